@@ -1,0 +1,148 @@
+"""ctypes binding of librt_gfx950.so: the C-ABI (include/rt_capi.h) and the
+host-API harness entry points (csrc/host/harness.cpp).
+
+The library is never built or substituted here: if it is missing, loading
+fails with an error that names the build command.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librt_gfx950.so")
+
+RT_COUNTER_NAMES = ["primary", "shadow", "secondary", "node", "tri", "sphere", "mesh_entry", "shade_mesh", "shade_sphere"]
+RT_COUNTER_CNT = 16
+RT_MAX_DEPTH = 15
+RT_STACK_ENTRIES = 32
+
+
+class RtVertex(C.Structure):
+    _fields_ = [("normal", C.c_float * 3), ("tangent", C.c_float * 3), ("bitangent", C.c_float * 3),
+                ("texCoord", C.c_float * 2), ("position", C.c_float * 3)]
+
+
+class RtTriangle(C.Structure):
+    _fields_ = [("i", C.c_int32 * 3)]
+
+
+class RtLinearNode(C.Structure):
+    _fields_ = [("bbmin", C.c_float * 3), ("bbmax", C.c_float * 3), ("offset", C.c_int32), ("primCnt", C.c_uint16),
+                ("axis", C.c_uint8), ("pad", C.c_uint8)]
+
+
+class RtTexture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("data", C.POINTER(C.c_ubyte)), ("mode", C.c_int32)]
+
+
+class RtMaterial(C.Structure):
+    _fields_ = [("materialType", C.c_int32), ("ior", C.c_float), ("Kd", C.c_float), ("Ks", C.c_float),
+                ("diffuseColor", C.c_float * 3), ("specularExponent", C.c_float)]
+
+
+class RtLight(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("intensity", C.c_float * 3), ("power", C.c_float)]
+
+
+class RtMesh(C.Structure):
+    _fields_ = [("triangleCnt", C.c_int32), ("triangles", C.POINTER(RtTriangle)), ("vertexCnt", C.c_int32),
+                ("vertices", C.POINTER(RtVertex)), ("diffuse", RtTexture), ("normals", RtTexture), ("specular", RtTexture),
+                ("nodeCnt", C.c_int32), ("nodes", C.POINTER(RtLinearNode)), ("transformInverse", C.c_float * 16)]
+
+
+class RtShape(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("center", C.c_float * 3), ("radius", C.c_float), ("radius2", C.c_float),
+                ("meshIdx", C.c_int32), ("material", RtMaterial), ("bbmin", C.c_float * 3), ("bbmax", C.c_float * 3),
+                ("tag", C.c_int32)]
+
+
+class RtSceneDesc(C.Structure):
+    _fields_ = [("lights", C.POINTER(RtLight)), ("lightCnt", C.c_int32), ("shapes", C.POINTER(RtShape)),
+                ("shapeCnt", C.c_int32), ("meshes", C.POINTER(RtMesh)), ("meshCnt", C.c_int32),
+                ("nodes", C.POINTER(RtLinearNode)), ("nodeCnt", C.c_int32)]
+
+
+class RtDeviceOpts(C.Structure):
+    _fields_ = [("imageAspectRatio", C.c_float), ("scale", C.c_float), ("width", C.c_int32), ("height", C.c_int32),
+                ("backgroundColor", C.c_float * 3), ("shadowBias", C.c_float), ("blockSize", C.c_int32),
+                ("maxDepth", C.c_int32), ("samples", C.c_int32), ("gammaCorrection", C.c_uint8),
+                ("useSceneBvh", C.c_uint8), ("useMeshBvhs", C.c_uint8), ("pad_", C.c_uint8)]
+
+
+class RtCamera(C.Structure):
+    _fields_ = [("orig", C.c_float * 3), ("camera", C.c_float * 16)]
+
+
+class RtFrameAux(C.Structure):
+    _fields_ = [("hitKeys", C.c_void_p), ("counters", C.c_void_p), ("tileFirst", C.c_int32), ("tileStride", C.c_int32)]
+
+
+assert C.sizeof(RtVertex) == 56 and C.sizeof(RtLinearNode) == 32 and C.sizeof(RtDeviceOpts) == 48
+assert C.sizeof(RtLight) == 28 and C.sizeof(RtMaterial) == 32 and C.sizeof(RtTriangle) == 12
+
+# name -> (restype, argtypes); every symbol include/rt_capi.h declares
+C_ABI = {
+    "rt_create": (C.c_void_p, [C.c_int]),
+    "rt_destroy": (None, [C.c_void_p]),
+    "rt_last_error": (C.c_char_p, [C.c_void_p]),
+    "rt_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rt_sync": (C.c_int, [C.c_void_p]),
+    "rt_scene_upload": (C.c_void_p, [C.c_void_p, C.POINTER(RtSceneDesc)]),
+    "rt_scene_pack": (C.c_int, [C.c_void_p, C.POINTER(RtSceneDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "rt_blob_free": (None, [C.c_void_p]),
+    "rt_scene_adopt_blob": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rt_scene_blob": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "rt_scene_set_lights": (C.c_int, [C.c_void_p, C.POINTER(RtLight), C.c_int]),
+    "rt_scene_free": (None, [C.c_void_p]),
+    "rt_surface_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "rt_surface_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]),
+    "rt_surface_free": (None, [C.c_void_p, C.c_void_p]),
+    "rt_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "rt_device_download": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rt_device_zero": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rt_device_free": (None, [C.c_void_p, C.c_void_p]),
+    "rt_render": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RtDeviceOpts), C.POINTER(RtCamera), C.c_void_p, C.c_size_t,
+                            C.c_int, C.POINTER(RtFrameAux)]),
+    "rt_timing_reset": (C.c_int, [C.c_void_p]),
+    "rt_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+}
+
+HARNESS = {
+    "rth_last_error": (C.c_char_p, []),
+    "rth_scene_create": (C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]),
+    "rth_scene_free": (None, [C.c_void_p]),
+    "rth_scene_desc": (C.POINTER(RtSceneDesc), [C.c_void_p]),
+    "rth_scene_opts": (C.POINTER(RtDeviceOpts), [C.c_void_p]),
+    "rth_scene_camera": (C.POINTER(RtCamera), [C.c_void_p]),
+    "rth_scene_triangles": (C.c_int, [C.c_void_p]),
+    "rth_scene_bvh_depth": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rth_scene_rotate_lights": (None, [C.c_void_p, C.c_float]),
+    "rth_scene_set_camera": (None, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rth_write_png": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
+    "rth_floats_to_bytes": (None, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rth_read_png": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rth_bvh_triangles": (C.c_int, [C.POINTER(RtVertex), C.c_int, C.POINTER(RtTriangle), C.c_int, C.c_int, C.c_int,
+                                    C.POINTER(RtLinearNode), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rth_mat_inverse": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rth_selftest": (C.c_int, [C.c_char_p, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads librt_gfx950.so (once) and types every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m cudaraytracer_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for table in (C_ABI, HARNESS):
+        for name, (res, args) in table.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,234 @@
+"""Thin Python mirror of the host API: HostScene (a scene built by the C++
+RayTracer / DeviceMesh / BVH::BvhFactory classes) and Context (one GPU, all
+calls going through the C-ABI)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+class RtError(RuntimeError):
+    pass
+
+
+class HostScene:
+    """A benchmark scene assembled on the host (csrc/host/harness.cpp).
+
+    name: cubes | soup | heightfield | mixed | barrel
+    tight_bvh: start BVH box unions from a true empty box instead of the
+    reference's FLT_MIN-clamped one (same hits except ties, far fewer tests).
+    """
+
+    def __init__(self, name, width, height, size=0, lights=0, max_depth=0, asset_dir=None, tight_bvh=False):
+        self.lib = N.load()
+        self.h = self.lib.rth_scene_create(name.encode(), width, height, size, lights, max_depth,
+                                           asset_dir.encode() if asset_dir else None, 1 if tight_bvh else 0)
+        if not self.h:
+            raise RtError(self.lib.rth_last_error().decode())
+        self.name = name
+
+    def close(self):
+        if self.h:
+            self.lib.rth_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def desc(self):
+        return self.lib.rth_scene_desc(self.h)
+
+    @property
+    def opts(self):
+        """Pointer to the scene's DeviceOpts (mutable: opts.contents.maxDepth = 2)."""
+        return self.lib.rth_scene_opts(self.h)
+
+    @property
+    def camera(self):
+        return self.lib.rth_scene_camera(self.h)
+
+    @property
+    def width(self):
+        return self.opts.contents.width
+
+    @property
+    def height(self):
+        return self.opts.contents.height
+
+    @property
+    def triangles(self):
+        return self.lib.rth_scene_triangles(self.h)
+
+    def bvh_depth(self):
+        a, b = C.c_int(), C.c_int()
+        self.lib.rth_scene_bvh_depth(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def rotate_lights(self, dt):
+        self.lib.rth_scene_rotate_lights(self.h, dt)
+
+    def set_camera(self, pos, direction):
+        p = (C.c_float * 3)(*pos)
+        d = (C.c_float * 3)(*direction)
+        self.lib.rth_scene_set_camera(self.h, p, d)
+
+
+def tiles_of_rank(width, height, rank, world, tile=8):
+    """Tile ids (row-major over 8x8 tiles) rendered by `rank` of `world`: t = rank, rank+world, ..."""
+    tx = (width + tile - 1) // tile
+    ty = (height + tile - 1) // tile
+    return np.arange(rank, tx * ty, world, dtype=np.int64), tx, ty
+
+
+class Context:
+    """One GPU. Owns device-side scenes, surfaces and aux buffers via the C-ABI."""
+
+    def __init__(self, device=0):
+        self.lib = N.load()
+        self.ctx = self.lib.rt_create(device)
+        if not self.ctx:
+            raise RtError("rt_create: " + self.lib.rt_last_error(None).decode())
+        self._allocs = []
+        self._scenes = []
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RtError(f"{what} failed ({rc}): {self.lib.rt_last_error(self.ctx).decode()}")
+
+    def close(self):
+        if not self.ctx:
+            return
+        for s in self._scenes:
+            self.lib.rt_scene_free(s)
+        for p in self._allocs:
+            self.lib.rt_device_free(self.ctx, p)
+        self._scenes, self._allocs = [], []
+        self.lib.rt_destroy(self.ctx)
+        self.ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- scene -------------------------------------------------------------
+    def upload(self, scene_or_desc):
+        desc = scene_or_desc.desc if isinstance(scene_or_desc, HostScene) else scene_or_desc
+        s = self.lib.rt_scene_upload(self.ctx, desc)
+        if not s:
+            raise RtError("rt_scene_upload: " + self.lib.rt_last_error(self.ctx).decode())
+        self._scenes.append(s)
+        return s
+
+    def adopt_blob(self, dev_ptr, nbytes):
+        s = self.lib.rt_scene_adopt_blob(self.ctx, dev_ptr, nbytes)
+        if not s:
+            raise RtError("rt_scene_adopt_blob: " + self.lib.rt_last_error(self.ctx).decode())
+        self._scenes.append(s)
+        return s
+
+    def scene_blob(self, scene):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.rt_scene_blob(scene, C.byref(p), C.byref(n)), "rt_scene_blob")
+        return p.value, n.value
+
+    def pack(self, desc):
+        """Host-side flattening only: returns the blob as a numpy uint8 array."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.rt_scene_pack(self.ctx, desc, C.byref(p), C.byref(n)), "rt_scene_pack")
+        try:
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_ubyte)), shape=(n.value,)).copy()
+        finally:
+            self.lib.rt_blob_free(p)
+
+    def set_lights(self, scene, desc):
+        d = desc.contents if hasattr(desc, "contents") else desc
+        self._check(self.lib.rt_scene_set_lights(scene, d.lights, d.lightCnt), "rt_scene_set_lights")
+
+    def free_scene(self, scene):
+        self._scenes.remove(scene)
+        self.lib.rt_scene_free(scene)
+
+    # -- buffers -----------------------------------------------------------
+    def surface(self, width, height):
+        p, pitch = C.c_void_p(), C.c_size_t()
+        self._check(self.lib.rt_surface_create(self.ctx, width, height, C.byref(p), C.byref(pitch)), "rt_surface_create")
+        self._allocs.append(p.value)
+        return p.value, pitch.value
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self._check(self.lib.rt_device_alloc(self.ctx, nbytes, C.byref(p)), "rt_device_alloc")
+        self._allocs.append(p.value)
+        return p.value
+
+    def free(self, ptr):
+        self._allocs.remove(ptr)
+        self.lib.rt_device_free(self.ctx, ptr)
+
+    def zero(self, ptr, nbytes):
+        self._check(self.lib.rt_device_zero(self.ctx, ptr, nbytes), "rt_device_zero")
+
+    def download_surface(self, surf, pitch, width, height):
+        out = np.empty((height, width, 4), dtype=np.float32)
+        self._check(self.lib.rt_surface_download(self.ctx, surf, pitch, width, height, out.ctypes.data), "rt_surface_download")
+        return out
+
+    def download(self, ptr, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        self._check(self.lib.rt_device_download(self.ctx, ptr, out.nbytes, out.ctypes.data), "rt_device_download")
+        return out
+
+    # -- rendering ---------------------------------------------------------
+    def render(self, scene, opts, camera, surf, pitch, hit_keys=None, counters=None, tile_first=0, tile_stride=1):
+        aux = N.RtFrameAux(hit_keys, counters, tile_first, tile_stride)
+        o = opts.contents if hasattr(opts, "contents") else opts
+        self._check(self.lib.rt_render(self.ctx, scene, C.byref(o), camera, surf, pitch, o.blockSize, C.byref(aux)), "rt_render")
+
+    def sync(self):
+        self._check(self.lib.rt_sync(self.ctx), "rt_sync")
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.rt_set_stream(self.ctx, stream_ptr), "rt_set_stream")
+
+    def timing_reset(self):
+        self._check(self.lib.rt_timing_reset(self.ctx), "rt_timing_reset")
+
+    def timing_read(self):
+        ms, n = C.c_double(), C.c_int()
+        self._check(self.lib.rt_timing_read(self.ctx, C.byref(ms), C.byref(n)), "rt_timing_read")
+        return ms.value, n.value
+
+    def render_frame(self, host_scene, scene=None, want_keys=False, want_counters=False):
+        """Convenience: full frame of a HostScene -> (rgba[h,w,4], keys or None, counters dict or None)."""
+        own = scene is None
+        if own:
+            scene = self.upload(host_scene)
+        w, h = host_scene.width, host_scene.height
+        surf, pitch = self.surface(w, h)
+        keys = self.alloc(w * h * 16) if want_keys else None
+        cnt = self.alloc(N.RT_COUNTER_CNT * 8) if want_counters else None
+        try:
+            self.render(scene, host_scene.opts, host_scene.camera, surf, pitch, keys, cnt)
+            self.sync()
+            rgba = self.download_surface(surf, pitch, w, h)
+            k = self.download(keys, (h, w, 4), np.int32) if want_keys else None
+            c = None
+            if want_counters:
+                raw = self.download(cnt, (N.RT_COUNTER_CNT,), np.uint64)
+                c = {name: int(raw[i]) for i, name in enumerate(N.RT_COUNTER_NAMES)}
+            return rgba, k, c
+        finally:
+            self.free(surf)
+            if keys:
+                self.free(keys)
+            if cnt:
+                self.free(cnt)
+            if own:
+                self.free_scene(scene)

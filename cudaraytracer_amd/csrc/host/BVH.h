@@ -1,0 +1,190 @@
+// Host BVH builder of the API: BVH::BvhFactory<T> over triangles or shapes,
+// producing the flattened LinearNode array and the primitives in leaf order.
+// Same construction rule as the reference (cudaTracer/BVH.h:63-181):
+//   - a range becomes a leaf when it holds <= threshold primitives or when the
+//     centroids do not spread along the chosen axis;
+//   - the axis is the widest extent of the centroid bounds (empty-box start and
+//     tie rules of BoundingBox apply);
+//   - the range is cut in two equal halves with std::nth_element on the box
+//     centroid, so the tree is balanced and its depth is ceil(log2(n/threshold));
+//   - nodes are laid out depth first: first child at self + 1, second child by
+//     index.
+// The reference builds both children as arguments of one call, which leaves the
+// order to the compiler (BVH.h:146-149); MSVC and g++ both evaluate right to
+// left, so the second half is numbered first here, explicitly.
+//
+// Bounds mode.  REFERENCE_BOUNDS reproduces the reference builder bit for bit,
+// including its empty box whose max corner starts at FLT_MIN: every box is then
+// stretched up to ~0 on each axis, so geometry at negative coordinates gets
+// heavily overlapping nodes (correct images, but hundreds of extra node and
+// triangle tests per ray).  TIGHT_BOUNDS starts every union from a true empty
+// box (+FLT_MAX / -FLT_MAX) and is otherwise the same algorithm; hits are the
+// same except for equal-distance ties, which depend on visiting order.
+#ifndef RT_HOST_BVH_H
+#define RT_HOST_BVH_H
+
+#include <algorithm>
+#include <memory>
+#include <stdexcept>
+#include <vector>
+
+#include "BoundingBox.h"
+#include "Scene.h"
+
+namespace rt {
+namespace BVH {
+
+enum BoundsMode { REFERENCE_BOUNDS = 0, TIGHT_BOUNDS = 1 };
+
+inline BoundingBox emptyBox(BoundsMode mode) {
+    return mode == TIGHT_BOUNDS ? BoundingBox(Vec3f(FLT_MAX, FLT_MAX, FLT_MAX), Vec3f(-FLT_MAX, -FLT_MAX, -FLT_MAX)) : BoundingBox();
+}
+inline BoundingBox triangleBox(const Triangle& t, const std::vector<Vertex>& v, BoundsMode mode) {
+    if (mode == REFERENCE_BOUNDS) return BoundingBox(t, v);
+    BoundingBox b = emptyBox(mode);
+    for (int corner = 0; corner < 3; ++corner) b = BoundingBox::unionn(b, v[t[corner]].position);
+    return b;
+}
+
+struct PreNode {
+    int primIdx;
+    BoundingBox bb;
+    Vec3f centroid;
+    PreNode() : primIdx(-1), bb(Vec3f(-10.0f, -20.0f, -30.0f), Vec3f(-1.0f, -2.0f, -3.0f)), centroid(-1.0f, -2.0f, -3.0f) {}
+    PreNode(int i, BoundingBox bb) : primIdx(i), bb(bb), centroid(bb.centroid()) {}
+};
+
+struct InterNode {
+    BoundingBox bb;
+    InterNode* children[2] = {nullptr, nullptr};
+    int splitAxis = -1;
+    int firstPrimOffset = -1;
+    int primitiveCnt = -1;
+    enum NodeTypes { NOT_SET = -1, LEAF, INTERIOR };
+    NodeTypes nodeType = NOT_SET;
+
+    void leaf(int firstPrim, int primCnt, BoundingBox box) {
+        firstPrimOffset = firstPrim;
+        primitiveCnt = primCnt;
+        bb = box;
+        nodeType = LEAF;
+    }
+    void interior(int axis, int primCnt, InterNode* c0, InterNode* c1) {
+        children[0] = c0;
+        children[1] = c1;
+        bb = BoundingBox::unionn(c0->bb, c1->bb);
+        splitAxis = axis;
+        primitiveCnt = primCnt;
+        nodeType = INTERIOR;
+    }
+};
+
+template <typename T>
+class BvhFactory {
+   public:
+    std::vector<T> orderedPrims;
+    std::vector<int> orderedIdx;  // index into `primitives` of each ordered slot
+    std::vector<T> primitives;
+    std::vector<PreNode> primitiveInfo;
+    std::vector<LinearNode> nodes;
+    int threshold;
+    int depth = 0;  // levels below the root
+    BoundsMode boundsMode;
+
+    BvhFactory(const std::vector<Vertex>& vertices, const std::vector<Triangle>& prims, int threshold,
+               BoundsMode mode = REFERENCE_BOUNDS)
+        : primitives(prims), threshold(threshold), boundsMode(mode) {
+        primitiveInfo.resize(prims.size());
+        for (int i = 0; i < (int)prims.size(); ++i) primitiveInfo[i] = PreNode(i, triangleBox(prims[i], vertices, mode));
+        build();
+    }
+    BvhFactory(const std::vector<Shape>& prims, BoundsMode mode = REFERENCE_BOUNDS)
+        : primitives(prims), threshold(1), boundsMode(mode) {
+        primitiveInfo.resize(prims.size());
+        for (int i = 0; i < (int)prims.size(); ++i) primitiveInfo[i] = PreNode(i, prims[i].bb);
+        build();
+    }
+
+   private:
+    std::vector<std::unique_ptr<InterNode>> pool;
+
+    void build() {
+        if (primitives.empty()) throw std::invalid_argument("BvhFactory: no primitives");
+        orderedPrims.reserve(primitives.size());
+        orderedIdx.reserve(primitives.size());
+        int totalNodes = 0;
+        InterNode* root = recursive(0, (int)primitives.size(), totalNodes, 0);
+        nodes = std::vector<LinearNode>(totalNodes);
+        int offset = 0;
+        flattenBvhTree(root, &offset);
+        pool.clear();
+    }
+
+    InterNode* recursive(const int start, const int end, int& totalNodes, int level) {
+        pool.emplace_back(new InterNode());
+        InterNode* node = pool.back().get();
+        totalNodes++;
+        depth = (std::max)(depth, level);
+        BoundingBox bb = emptyBox(boundsMode);
+        for (int i = start; i < end; ++i) bb = BoundingBox::unionn(bb, primitiveInfo[i].bb);
+
+        const int primCnt = end - start;
+        if (primCnt <= threshold) {
+            leaf(bb, primCnt, start, end, node);
+            return node;
+        }
+        BoundingBox centroidBounds = emptyBox(boundsMode);
+        for (int i = start; i < end; ++i)
+            centroidBounds = BoundingBox::unionn(centroidBounds, primitiveInfo[i].bb.centroid());
+        const int dim = centroidBounds.maxExtent();
+        if (centroidBounds.bbmax[dim] == centroidBounds.bbmin[dim]) {
+            leaf(bb, primCnt, start, end, node);
+            return node;
+        }
+        interior(primCnt, start, end, dim, node, totalNodes, level);
+        return node;
+    }
+
+    void interior(const int primCnt, const int start, const int end, const int dim, InterNode* node, int& totalNodes,
+                  int level) {
+        const int mid = (start + end) / 2;
+        std::nth_element(primitiveInfo.begin() + start, primitiveInfo.begin() + mid, primitiveInfo.begin() + end,
+                         [dim](const PreNode& a, const PreNode& b) { return a.bb.centroid()[dim] < b.bb.centroid()[dim]; });
+        InterNode* second = recursive(mid, end, totalNodes, level + 1);
+        InterNode* first = recursive(start, mid, totalNodes, level + 1);
+        node->interior(dim, primCnt, first, second);
+    }
+
+    void leaf(const BoundingBox& bb, const int primCnt, const int start, const int end, InterNode* node) {
+        if (primCnt > 65535) throw std::length_error("BvhFactory: leaf exceeds the 16-bit primitive count of LinearNode");
+        const int firstPrimOffset = (int)orderedPrims.size();
+        for (int i = start; i < end; ++i) {
+            const int idx = primitiveInfo[i].primIdx;
+            orderedPrims.push_back(primitives[idx]);
+            orderedIdx.push_back(idx);
+        }
+        node->leaf(firstPrimOffset, primCnt, bb);
+    }
+
+    int flattenBvhTree(InterNode* node, int* offset) {
+        LinearNode* linearNode = &nodes[*offset];
+        linearNode->bb = node->bb;
+        const int myOffset = (*offset)++;
+        if (node->nodeType == InterNode::LEAF) {
+            linearNode->primitivesOffset = node->firstPrimOffset;
+            linearNode->primtiveCnt = (uint16_t)node->primitiveCnt;
+        } else if (node->nodeType == InterNode::INTERIOR) {
+            linearNode->axis = (uint8_t)node->splitAxis;
+            linearNode->primtiveCnt = 0;
+            flattenBvhTree(node->children[0], offset);
+            linearNode->secondChildOffset = flattenBvhTree(node->children[1], offset);
+        } else {
+            throw std::logic_error("BvhFactory: unclassified node");
+        }
+        return myOffset;
+    }
+};
+
+}  // namespace BVH
+}  // namespace rt
+#endif

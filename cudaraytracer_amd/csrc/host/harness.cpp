@@ -1,0 +1,420 @@
+// harness.cpp - C entry points (rth_*) that let the Python bench / tests drive
+// the C++ host API: build one of the benchmark scenes with RayTracer /
+// DeviceMesh / BVH::BvhFactory, expose its flat RtSceneDesc + options + camera,
+// rotate lights, dump PNGs, and run the host-API known-answer tests.
+// Nothing here touches the GPU; rendering goes through include/rt_capi.h.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "CubeModelFactory.h"
+#include "ObjFileReader.h"
+#include "RayTracer.h"
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_error;
+
+// PCG32 (XSH-RR 64/32, O'Neill 2014): the generator every procedural scene uses.
+struct Pcg32 {
+    uint64_t state = 0, inc = 0;
+    explicit Pcg32(uint64_t seed, uint64_t seq = 54u) {
+        inc = (seq << 1u) | 1u;
+        next();
+        state += seed;
+        next();
+    }
+    uint32_t next() {
+        const uint64_t old = state;
+        state = old * 6364136223846793005ULL + inc;
+        const uint32_t xorshifted = (uint32_t)(((old >> 18u) ^ old) >> 27u);
+        const uint32_t rot = (uint32_t)(old >> 59u);
+        return (xorshifted >> rot) | (xorshifted << ((32 - rot) & 31));
+    }
+    float uniform() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }  // [0, 1)
+    float uniform(float lo, float hi) { return lo + (hi - lo) * uniform(); }
+};
+
+TextureSource checker(unsigned n, const unsigned char a[3], const unsigned char b[3]) {
+    std::vector<unsigned char> px((size_t)n * n * 4);
+    for (unsigned y = 0; y < n; ++y)
+        for (unsigned x = 0; x < n; ++x) {
+            const unsigned char* c = ((x ^ y) & 1) ? a : b;
+            unsigned char* p = &px[((size_t)y * n + x) * 4];
+            p[0] = c[0];
+            p[1] = c[1];
+            p[2] = c[2];
+            p[3] = 255;
+        }
+    return TextureSource(n, n, std::move(px));
+}
+// smooth bumps for a procedural normal map: RGB = (n * 0.5 + 0.5) * 255
+TextureSource bumpNormals(unsigned n) {
+    std::vector<unsigned char> px((size_t)n * n * 4);
+    for (unsigned y = 0; y < n; ++y)
+        for (unsigned x = 0; x < n; ++x) {
+            const float fx = 0.35f * std::sin(6.2831853f * x / n * 2.0f), fy = 0.35f * std::cos(6.2831853f * y / n * 2.0f);
+            unsigned char* p = &px[((size_t)y * n + x) * 4];
+            p[0] = (unsigned char)((fx * 0.5f + 0.5f) * 255.0f);
+            p[1] = (unsigned char)((fy * 0.5f + 0.5f) * 255.0f);
+            p[2] = 255;
+            p[3] = 255;
+        }
+    return TextureSource(n, n, std::move(px));
+}
+TextureSource greyRamp(unsigned n) {
+    std::vector<unsigned char> px((size_t)n * n * 4);
+    for (unsigned y = 0; y < n; ++y)
+        for (unsigned x = 0; x < n; ++x) {
+            unsigned char* p = &px[((size_t)y * n + x) * 4];
+            p[0] = p[1] = p[2] = (unsigned char)(40 + (x * 7 + y * 13) % 200);
+            p[3] = 255;
+        }
+    return TextureSource(n, n, std::move(px));
+}
+
+void ringLights(RayTracer& rt, int count, uint64_t seed) {
+    // deterministic stand-in for the reference's rand()-driven ring of lights
+    // (cudaTracer/RayTracer.cpp:85-101): radius U(10,50), height U(0,25),
+    // intensity U(0,.5)^3, power U(0,25)
+    Pcg32 rng(seed);
+    const float radStep = (2.0f * PI) / count;
+    for (int i = 0; i < count; ++i) {
+        const float power = rng.uniform(0, 25.0f);
+        const Vec3f position(std::sin(i * radStep) * rng.uniform(10, 50), rng.uniform(0, 25.0f),
+                             std::cos(i * radStep) * rng.uniform(10, 50));
+        const Vec3f intensity(rng.uniform(0, 0.5f), rng.uniform(0, 0.5f), rng.uniform(0, 0.5f));
+        rt.addLight(Light(position, intensity, power));
+    }
+}
+
+using BVH::BoundsMode;
+
+Options baseOptions(int width, int height, float fov, int maxDepth) {
+    Options o = loadDefaults();
+    setView(o, width, height, fov);
+    o.device.maxDepth = maxDepth;
+    return o;
+}
+
+// cfg "cubes": n x n grid of unit cubes (CubeModelFactory tables), each its own
+// mesh with its own BVH, under a scene BVH; 1x1 textures; 4 fixed lights.
+std::unique_ptr<RayTracer> buildCubes(int width, int height, int n, int lightCnt, int maxDepth, BoundsMode bm) {
+    if (n < 1) n = 16;
+    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 90, maxDepth), bm);
+    const std::vector<Vertex> verts = CubeModelFactory::createVertices();
+    const std::vector<int> inds = CubeModelFactory::createIndicies();
+    Material mtl;
+    mtl.materialType = Material::DIFFUSE_AND_GLOSSY;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const Mat44f transform =
+                Mat44f::scale(0.4f, 0.4f, 0.4f) * Mat44f::translate(1.2f * i - 0.6f * n, -2.0f, 6.0f + 1.2f * j);
+            rt->addMesh(std::make_unique<DeviceMesh>(verts, inds, 12, TextureSource::solid(255, 255, 255),
+                                                     TextureSource::solid(128, 128, 255), TextureSource::solid(255, 255, 255),
+                                                     Texture::CLAMP, mtl, transform, bm));
+        }
+    static const Light table[4] = {Light(Vec3f(0, 8, 0), Vec3f(0.5f, 0.5f, 0.5f), 20), Light(Vec3f(-12, 6, 10), Vec3f(0.5f, 0.3f, 0.2f), 25),
+                                   Light(Vec3f(12, 10, 20), Vec3f(0.2f, 0.3f, 0.5f), 25), Light(Vec3f(0, 3, -4), Vec3f(0.3f, 0.3f, 0.3f), 10)};
+    if (lightCnt < 1 || lightCnt > 4) lightCnt = 4;
+    for (int i = 0; i < lightCnt; ++i) rt->addLight(table[i]);
+    rt->finalizeScene();
+    return rt;
+}
+
+// cfg "soup": N random triangles in one mesh (de-indexed, like the OBJ reader
+// produces): centres U[-50,50]^3, two edges U[-0.75,0.75]^3, face normals,
+// UVs (0,0)(1,0)(0,1); PCG32 seed 1234; 16x16 procedural textures.
+std::unique_ptr<RayTracer> buildSoup(int width, int height, int triCnt, int lightCnt, int maxDepth, BoundsMode bm) {
+    if (triCnt < 1) triCnt = 1000000;
+    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 60, maxDepth), bm);
+    Pcg32 rng(1234);
+    std::vector<Vertex> verts;
+    std::vector<int> inds;
+    verts.reserve((size_t)triCnt * 3);
+    inds.reserve((size_t)triCnt * 3);
+    for (int t = 0; t < triCnt; ++t) {
+        const Vec3f c(rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(-50, 50));
+        const Vec3f e1(rng.uniform(-0.75f, 0.75f), rng.uniform(-0.75f, 0.75f), rng.uniform(-0.75f, 0.75f));
+        const Vec3f e2(rng.uniform(-0.75f, 0.75f), rng.uniform(-0.75f, 0.75f), rng.uniform(-0.75f, 0.75f));
+        const Vec3f n = e1.cross(e2).normalized();
+        verts.push_back(Vertex(c, n, Vec2f(0.0f, 0.0f)));
+        verts.push_back(Vertex(c + e1, n, Vec2f(1.0f, 0.0f)));
+        verts.push_back(Vertex(c + e2, n, Vec2f(0.0f, 1.0f)));
+        for (int k = 0; k < 3; ++k) inds.push_back(3 * t + k);
+    }
+    const unsigned char ca[3] = {230, 200, 90}, cb[3] = {60, 110, 200};
+    Material mtl;
+    mtl.materialType = Material::DIFFUSE_AND_GLOSSY;
+    rt->addMesh(std::make_unique<DeviceMesh>(std::move(verts), std::move(inds), triCnt, checker(16, ca, cb), bumpNormals(16), greyRamp(16),
+                                             Texture::WRAP, mtl, Mat44f::identity(), bm));
+    rt->camera.setPosition(0, 0, -120);
+    rt->camera.update();
+    if (lightCnt <= 1) {
+        rt->addLight(Light(Vec3f(0, 200, -120), Vec3f(0.5f, 0.5f, 0.5f), 25));
+    } else {
+        Pcg32 lr(77);
+        for (int i = 0; i < lightCnt; ++i)
+            rt->addLight(Light(Vec3f(lr.uniform(-150, 150), lr.uniform(100, 250), lr.uniform(-200, -80)),
+                               Vec3f(lr.uniform(0.1f, 0.5f), lr.uniform(0.1f, 0.5f), lr.uniform(0.1f, 0.5f)), lr.uniform(10, 40)));
+    }
+    rt->finalizeScene();
+    return rt;
+}
+
+// cfg "heightfield": side x side quads of a sinusoidally displaced, jittered
+// height field in ONE mesh (2 triangles per quad, de-indexed).
+std::unique_ptr<RayTracer> buildHeightfield(int width, int height, int triCnt, int lightCnt, int maxDepth, BoundsMode bm) {
+    int side = (int)std::floor(std::sqrt((triCnt < 2 ? 9999392 : triCnt) / 2.0));
+    if (side < 1) side = 1;
+    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 60, maxDepth), bm);
+    Pcg32 rng(1234);
+    const float extent = 200.0f, cell = extent / side;
+    std::vector<float> hgt((size_t)(side + 1) * (side + 1));
+    for (int z = 0; z <= side; ++z)
+        for (int x = 0; x <= side; ++x) {
+            const float fx = x * cell, fz = z * cell;
+            hgt[(size_t)z * (side + 1) + x] =
+                4.0f * std::sin(fx * 0.11f) * std::cos(fz * 0.07f) + 1.5f * std::sin(fx * 0.53f + fz * 0.31f) + rng.uniform(-0.05f, 0.05f);
+        }
+    auto P = [&](int x, int z) { return Vec3f(x * cell - extent * 0.5f, hgt[(size_t)z * (side + 1) + x], z * cell); };
+    std::vector<Vertex> verts;
+    std::vector<int> inds;
+    verts.reserve((size_t)side * side * 6);
+    inds.reserve((size_t)side * side * 6);
+    auto emit = [&](Vec3f a, Vec3f b, Vec3f c, Vec2f ta, Vec2f tb, Vec2f tc) {
+        const Vec3f n = (b - a).cross(c - a).normalized();
+        const int base = (int)verts.size();
+        verts.push_back(Vertex(a, n, ta));
+        verts.push_back(Vertex(b, n, tb));
+        verts.push_back(Vertex(c, n, tc));
+        for (int k = 0; k < 3; ++k) inds.push_back(base + k);
+    };
+    for (int z = 0; z < side; ++z)
+        for (int x = 0; x < side; ++x) {
+            // counter-clockwise seen from above, so the upward face is the front face
+            emit(P(x, z), P(x, z + 1), P(x + 1, z), Vec2f(0, 0), Vec2f(0, 1), Vec2f(1, 0));
+            emit(P(x + 1, z), P(x, z + 1), P(x + 1, z + 1), Vec2f(1, 0), Vec2f(0, 1), Vec2f(1, 1));
+        }
+    const unsigned char ca[3] = {120, 170, 80}, cb[3] = {90, 120, 60};
+    Material mtl;
+    const int made = (int)inds.size() / 3;
+    rt->addMesh(std::make_unique<DeviceMesh>(std::move(verts), std::move(inds), made, checker(16, ca, cb), bumpNormals(16), greyRamp(16),
+                                             Texture::WRAP, mtl, Mat44f::identity(), bm));
+    rt->camera.setPosition(0, 45, -30);
+    rt->camera.setDirection(Vec3f(0, -0.45f, 1.0f));
+    if (lightCnt < 1) lightCnt = 1;
+    rt->addLight(Light(Vec3f(30, 120, 60), Vec3f(0.5f, 0.5f, 0.45f), 120));
+    Pcg32 lr(78);
+    for (int i = 1; i < lightCnt; ++i)
+        rt->addLight(Light(Vec3f(lr.uniform(-90, 90), lr.uniform(60, 140), lr.uniform(10, 190)),
+                           Vec3f(lr.uniform(0.1f, 0.4f), lr.uniform(0.1f, 0.4f), lr.uniform(0.1f, 0.4f)), lr.uniform(40, 120)));
+    rt->finalizeScene();
+    return rt;
+}
+
+// cfg "mixed": the reference's default scene shape - sphere field + mirror +
+// glass + textured plane + three mesh instances - with a deterministic light
+// ring.  With an asset directory the plane uses pattern_106 and the meshes are
+// the metal barrel; without one, procedural textures and cubes stand in.
+std::unique_ptr<RayTracer> buildMixed(int width, int height, int lightCnt, int maxDepth, const std::string& assets, BoundsMode bm) {
+    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 90, maxDepth), bm);
+    rt->addSpheres();
+    const unsigned char ca[3] = {200, 200, 200}, cb[3] = {70, 70, 90};
+    if (!assets.empty()) {
+        const std::string t = assets + "/textures/pattern_106/";
+        rt->addPlane(t + "diffus.png", t + "normal.png", t + "specular.png");
+    } else {
+        rt->addPlane(checker(64, ca, cb), bumpNormals(64), greyRamp(64));
+    }
+    Material mtl;
+    mtl.materialType = Material::DIFFUSE_AND_GLOSSY;
+    const float pos[3][3] = {{0.5f, -3, 9}, {-2, -3, 5}, {-4, -3, 4}};
+    if (!assets.empty()) {
+        // cudaTracer/RayTracer.cpp:158-186 with the barrel that ships (the plastic one has no .obj)
+        const Mat44f scale = Mat44f::scale(1 / 50.0f, 1 / 50.0f, 1 / 50.0f);
+        const std::vector<model::Model> models = ObjFileReader().readFile(assets + "/models/metalBarrel/", "metal_barrel.obj", false);
+        if (models.empty()) throw std::runtime_error("metal_barrel.obj: no model read");
+        for (int k = 0; k < 3; ++k)
+            rt->addMesh(std::make_unique<DeviceMesh>(models[0], mtl, scale * Mat44f::translate(pos[k][0], pos[k][1], pos[k][2]), bm));
+    } else {
+        const std::vector<Vertex> verts = CubeModelFactory::createVertices();
+        const std::vector<int> inds = CubeModelFactory::createIndicies();
+        for (int k = 0; k < 3; ++k)
+            rt->addMesh(std::make_unique<DeviceMesh>(verts, inds, 12, checker(8, ca, cb), bumpNormals(8), greyRamp(8), Texture::CLAMP, mtl,
+                                                     Mat44f::scale(0.6f, 1.0f, 0.6f) * Mat44f::translate(pos[k][0], pos[k][1] + 1.0f, pos[k][2]), bm));
+    }
+    ringLights(*rt, lightCnt < 1 ? 16 : lightCnt, 4242);
+    rt->finalizeScene();
+    return rt;
+}
+
+// cfg "barrel": the OBJ asset with its three PNG maps + textured plane + mirror
+// and glass balls + a mirror-material barrel instance.
+std::unique_ptr<RayTracer> buildBarrel(int width, int height, int lightCnt, int maxDepth, const std::string& assets, BoundsMode bm) {
+    if (assets.empty()) throw std::invalid_argument("scene 'barrel' needs an asset directory");
+    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 90, maxDepth), bm);
+    const Mat44f scale = Mat44f::scale(1 / 50.0f, 1 / 50.0f, 1 / 50.0f);
+    const std::vector<model::Model> models = ObjFileReader().readFile(assets + "/models/metalBarrel/", "metal_barrel.obj", false);
+    if (models.empty()) throw std::runtime_error("metal_barrel.obj: no model read");
+    Material mtl;
+    rt->addMesh(std::make_unique<DeviceMesh>(models[0], mtl, scale * Mat44f::translate(0.5f, -3, 5), bm));
+    rt->addMesh(std::make_unique<DeviceMesh>(models[0], mtl, scale * Mat44f::translate(-2, -3, 6), bm));
+    Material mirror;
+    mirror.materialType = Material::REFLECTION;
+    mirror.ior = 64;
+    rt->addMesh(std::make_unique<DeviceMesh>(models[0], mirror, scale * Mat44f::translate(-4.5f, -3, 7), bm));
+    const std::string t = assets + "/textures/pattern_106/";
+    rt->addPlane(t + "diffus.png", t + "normal.png", t + "specular.png");
+    Shape mirrorBall = Shape(Sphere(Vec3f(2.5f, 1.0f, 6.0f), 1.0f));
+    mirrorBall.material.ior = 64;
+    mirrorBall.material.materialType = Material::REFLECTION;
+    rt->addShape(mirrorBall);
+    Shape glassBall = Shape(Sphere(Vec3f(1.5f, -1.5f, 4.5f), 1.5f));
+    glassBall.material.ior = 1.5f;
+    glassBall.material.materialType = Material::REFLECTION_AND_REFRACTION;
+    rt->addShape(glassBall);
+    ringLights(*rt, lightCnt < 1 ? 10 : lightCnt, 99);
+    rt->finalizeScene();
+    return rt;
+}
+
+}  // namespace
+
+struct rth_scene {
+    std::unique_ptr<RayTracer> rt;
+    std::vector<RtShape> shapeStore;
+    std::vector<RtMesh> meshStore;
+    RtSceneDesc desc;
+    RtCamera camera;
+    void refresh() {
+        Scene s = rt->currentScene();
+        desc = s.describe(shapeStore, meshStore);
+        camera = s.cameraDesc();
+    }
+};
+
+extern "C" {
+
+const char* rth_last_error(void) { return g_error.c_str(); }
+
+// name: "cubes" | "soup" | "heightfield" | "mixed" | "barrel".  `size` = grid side
+// (cubes) or triangle count (soup, heightfield); 0 = the benchmark default.  flags bit 0: build every BVH
+// with tight bounds instead of the reference's FLT_MIN-clamped ones.
+rth_scene* rth_scene_create(const char* name, int width, int height, int size, int lightCnt, int maxDepth, const char* assetDir,
+                            int flags) {
+    try {
+        const BoundsMode bm = (flags & 1) ? BVH::TIGHT_BOUNDS : BVH::REFERENCE_BOUNDS;
+        const std::string n = name ? name : "";
+        const std::string assets = assetDir ? assetDir : "";
+        std::unique_ptr<RayTracer> rt;
+        if (n == "cubes")
+            rt = buildCubes(width, height, size, lightCnt, maxDepth, bm);
+        else if (n == "soup")
+            rt = buildSoup(width, height, size, lightCnt, maxDepth, bm);
+        else if (n == "heightfield")
+            rt = buildHeightfield(width, height, size, lightCnt, maxDepth, bm);
+        else if (n == "mixed")
+            rt = buildMixed(width, height, lightCnt, maxDepth, assets, bm);
+        else if (n == "barrel")
+            rt = buildBarrel(width, height, lightCnt, maxDepth, assets, bm);
+        else
+            throw std::invalid_argument("unknown scene '" + n + "'");
+        auto* h = new rth_scene();
+        h->rt = std::move(rt);
+        h->refresh();
+        return h;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return nullptr;
+    }
+}
+void rth_scene_free(rth_scene* h) { delete h; }
+const RtSceneDesc* rth_scene_desc(rth_scene* h) { return &h->desc; }
+RtDeviceOpts* rth_scene_opts(rth_scene* h) { return reinterpret_cast<RtDeviceOpts*>(&h->rt->options.device); }
+const RtCamera* rth_scene_camera(rth_scene* h) { return &h->camera; }
+int rth_scene_triangles(rth_scene* h) {
+    long long n = 0;
+    for (auto& m : h->rt->meshes) n += (long long)m->triangles.size();
+    return (int)n;
+}
+int rth_scene_bvh_depth(rth_scene* h, int* sceneDepth, int* meshDepth) {
+    int md = 0;
+    for (auto& m : h->rt->meshes) md = std::max(md, m->bvhDepth);
+    if (sceneDepth) *sceneDepth = h->rt->sceneBvhDepth;
+    if (meshDepth) *meshDepth = md;
+    return 0;
+}
+// RayTracer::updateLights (cudaTracer/RayTracer.cpp:259-267); desc->lights stays valid.
+void rth_scene_rotate_lights(rth_scene* h, float dt) {
+    h->rt->updateLights(dt);
+    h->refresh();
+}
+void rth_scene_set_camera(rth_scene* h, const float pos[3], const float dir[3]) {
+    h->rt->camera.setPosition(pos[0], pos[1], pos[2]);
+    h->rt->camera.setDirection(Vec3f(dir[0], dir[1], dir[2]));
+    h->refresh();
+}
+
+// PicDumper: float RGBA -> 8-bit (x256, clamped) -> PNG.
+int rth_write_png(const char* path, const float* rgba, int width, int height) {
+    std::vector<float> px(rgba, rgba + (size_t)width * height * 4);
+    return PicDumper(width, height).toDisk(px, path) ? 0 : -1;
+}
+void rth_floats_to_bytes(const float* rgba, size_t count, unsigned char* out) {
+    std::vector<float> px(rgba, rgba + count);
+    const std::vector<unsigned char> b = PicDumper::copyFloatsToCharVector(px);
+    std::memcpy(out, b.data(), count);
+}
+// PNG decode to RGBA8 (the texture ingest path); returns 0 and fills w/h; out may be NULL to query the size.
+int rth_read_png(const char* path, unsigned char* out, size_t outBytes, int* width, int* height) {
+    std::vector<unsigned char> px;
+    unsigned w = 0, h = 0;
+    std::string err;
+    if (!png::decodeFile(path, px, w, h, &err)) {
+        g_error = err;
+        return -1;
+    }
+    *width = (int)w;
+    *height = (int)h;
+    if (out) {
+        if (outBytes < px.size()) return -2;
+        std::memcpy(out, px.data(), px.size());
+    }
+    return 0;
+}
+
+// Host BVH build over a triangle list, for parity checks against the oracle's builder.
+int rth_bvh_triangles(const RtVertex* verts, int vertCnt, const RtTriangle* tris, int triCnt, int threshold, int tight,
+                      RtLinearNode* nodesOut, int* nodeCntOut, int* orderOut) {
+    try {
+        std::vector<Vertex> v(reinterpret_cast<const Vertex*>(verts), reinterpret_cast<const Vertex*>(verts) + vertCnt);
+        std::vector<Triangle> t(reinterpret_cast<const Triangle*>(tris), reinterpret_cast<const Triangle*>(tris) + triCnt);
+        BVH::BvhFactory<Triangle> bvh(v, t, threshold, tight ? BVH::TIGHT_BOUNDS : BVH::REFERENCE_BOUNDS);
+        std::memcpy(nodesOut, bvh.nodes.data(), bvh.nodes.size() * sizeof(LinearNode));
+        *nodeCntOut = (int)bvh.nodes.size();
+        std::memcpy(orderOut, bvh.orderedIdx.data(), bvh.orderedIdx.size() * sizeof(int));
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return -1;
+    }
+}
+void rth_mat_inverse(const float in[16], float out[16]) {
+    Mat44f m;
+    std::memcpy(m.x, in, 64);
+    const Mat44f r = m.inversed();
+    std::memcpy(out, r.x, 64);
+}
+
+// Host-API known-answer tests: the assertions of the reference's VectorTest.cpp,
+// Tests.cpp, BoundingBoxTest.cpp and BvhTest.cpp, applied to this library's
+// classes.  Returns the number of failed checks; `log` gets one line per case.
+int rth_selftest(char* log, int logLen);
+
+}  // extern "C"

@@ -1,0 +1,547 @@
+// rt_capi.cpp - implementation of the C-ABI declared in include/rt_capi.h:
+// context / stream management, flattening of an RtSceneDesc into the device
+// blob (rt_device_format.h), uploads, and the per-frame launch of the render
+// kernel.  Host code only; the kernels live in kernels/rt_kernels.hip.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_capi.h"
+#include "rt_device_format.h"
+
+namespace {
+
+thread_local std::string g_createError;
+
+struct TimedLaunch {
+    hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    int cuCount = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    unsigned int* tileQueue = nullptr;  // one 256-byte slot, zeroed before every launch
+    std::string error;
+    std::vector<TimedLaunch> launches;  // events of launches since the last reset
+    size_t launchesUsed = 0;
+    int gridBlocks[2][2] = {{0, 0}, {0, 0}};
+};
+
+struct rt_scene {
+    rt_ctx* ctx = nullptr;
+    unsigned char* blob = nullptr;
+    bool ownsBlob = false;
+    size_t bytes = 0;
+    BlobHeader header;
+};
+
+namespace {
+
+int fail(rt_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->error = buf;
+    else
+        g_createError = buf;
+    return code;
+}
+
+#define RT_HIP(ctx, call)                                                                          \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+int bind(rt_ctx* ctx) {
+    RT_HIP(ctx, hipSetDevice(ctx->device));
+    return RT_OK;
+}
+
+size_t alignUp(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+// Levels below the root of a flattened tree; also validates child / primitive ranges.
+int treeDepth(const RtLinearNode* nodes, int nodeCnt, int primCnt, int* maxLeafPrims, std::string* err) {
+    struct Item {
+        int idx, level;
+    };
+    std::vector<Item> todo;
+    todo.push_back({0, 0});
+    int depth = 0;
+    size_t visited = 0;
+    while (!todo.empty()) {
+        Item it = todo.back();
+        todo.pop_back();
+        if (it.idx < 0 || it.idx >= nodeCnt || ++visited > (size_t)nodeCnt) {
+            *err = "BVH node index out of range or cyclic";
+            return -1;
+        }
+        depth = std::max(depth, it.level);
+        const RtLinearNode& n = nodes[it.idx];
+        if (n.primCnt > 0) {
+            if (n.offset < 0 || (long long)n.offset + n.primCnt > primCnt) {
+                *err = "BVH leaf references primitives out of range";
+                return -1;
+            }
+            if (maxLeafPrims) *maxLeafPrims = std::max(*maxLeafPrims, (int)n.primCnt);
+        } else {
+            if (n.axis > 2) {
+                *err = "BVH interior node with bad axis";
+                return -1;
+            }
+            todo.push_back({it.idx + 1, it.level + 1});
+            todo.push_back({n.offset, it.level + 1});
+        }
+    }
+    return depth;
+}
+
+// Flattens `desc` into a host blob.  Returns RT_OK or an error (message in *err).
+int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string* err) {
+    auto bad = [&](const char* m) {
+        *err = m;
+        return RT_ERR_INVALID;
+    };
+    if (!d) return bad("null scene description");
+    if (d->shapeCnt < 1 || !d->shapes) return bad("scene without shapes");
+    if (d->lightCnt < 0 || (d->lightCnt > 0 && !d->lights)) return bad("bad light table");
+    if (d->nodeCnt < 1 || !d->nodes) return bad("scene without BVH nodes");
+    if (d->meshCnt < 0 || (d->meshCnt > 0 && !d->meshes)) return bad("bad mesh table");
+
+    BlobHeader hd;
+    std::memset(&hd, 0, sizeof hd);
+    hd.magic = RT_BLOB_MAGIC;
+    hd.version = RT_BLOB_VERSION;
+    hd.lightCnt = d->lightCnt;
+    hd.shapeCnt = d->shapeCnt;
+    hd.meshCnt = d->meshCnt;
+    hd.sceneNodeCnt = d->nodeCnt;
+
+    int maxLeafShapes = 0;
+    hd.sceneDepth = treeDepth(d->nodes, d->nodeCnt, d->shapeCnt, &maxLeafShapes, err);
+    if (hd.sceneDepth < 0) return RT_ERR_INVALID;
+    hd.maxLeafShapes = maxLeafShapes;
+
+    size_t cursor = sizeof(BlobHeader);
+    auto reserve = [&](size_t bytes) {
+        size_t at = alignUp(cursor);
+        cursor = at + bytes;
+        return at;
+    };
+    hd.offLights = reserve((size_t)std::max(d->lightCnt, 1) * sizeof(RtLight));
+    hd.offShapes = reserve((size_t)d->shapeCnt * sizeof(DevShape));
+    hd.offSceneNodes = reserve((size_t)d->nodeCnt * sizeof(RtLinearNode));
+    hd.offMeshes = reserve((size_t)std::max(d->meshCnt, 1) * sizeof(DevMesh));
+
+    std::vector<DevMesh> meshes(std::max(d->meshCnt, 0));
+    for (int mi = 0; mi < d->meshCnt; ++mi) {
+        const RtMesh& m = d->meshes[mi];
+        DevMesh& dm = meshes[mi];
+        std::memset(&dm, 0, sizeof dm);
+        if (m.triangleCnt < 1 || !m.triangles || m.vertexCnt < 1 || !m.vertices || m.nodeCnt < 1 || !m.nodes)
+            return bad("mesh with missing triangles, vertices or nodes");
+        for (int t = 0; t < m.triangleCnt; ++t)
+            for (int k = 0; k < 3; ++k)
+                if (m.triangles[t].i[k] < 0 || m.triangles[t].i[k] >= m.vertexCnt) return bad("triangle vertex index out of range");
+        int depth = treeDepth(m.nodes, m.nodeCnt, m.triangleCnt, nullptr, err);
+        if (depth < 0) return RT_ERR_INVALID;
+        hd.maxMeshDepth = std::max(hd.maxMeshDepth, depth);
+        std::memcpy(dm.inv, m.transformInverse, sizeof dm.inv);
+        dm.triangleCnt = m.triangleCnt;
+        dm.nodeCnt = m.nodeCnt;
+        dm.vertexCnt = m.vertexCnt;
+        dm.offNodes = reserve((size_t)m.nodeCnt * sizeof(RtLinearNode));
+        dm.offTriRecords = reserve((size_t)m.triangleCnt * sizeof(TriRecord));
+        dm.offVertices = reserve((size_t)m.vertexCnt * sizeof(RtVertex));
+        const RtTexture* tex[3] = {&m.diffuse, &m.normals, &m.specular};
+        for (int k = 0; k < 3; ++k) {
+            if (tex[k]->width < 1 || tex[k]->height < 1 || !tex[k]->data) return bad("mesh texture missing");
+            if (tex[k]->mode != RT_TEX_WRAP && tex[k]->mode != RT_TEX_CLAMP) return bad("bad texture addressing mode");
+            dm.texW[k] = tex[k]->width;
+            dm.texH[k] = tex[k]->height;
+            dm.texMode[k] = tex[k]->mode;
+            dm.offTex[k] = reserve((size_t)tex[k]->width * tex[k]->height * 4);
+        }
+    }
+    if (hd.sceneDepth + hd.maxMeshDepth > RT_STACK_ENTRIES) {
+        *err = "BVH too deep for the kernel's traversal stack (scene depth + mesh depth > RT_STACK_ENTRIES)";
+        return RT_ERR_LIMIT;
+    }
+    hd.totalBytes = alignUp(cursor);
+    out.assign(hd.totalBytes, 0);
+    unsigned char* base = out.data();
+
+    if (d->lightCnt) std::memcpy(base + hd.offLights, d->lights, (size_t)d->lightCnt * sizeof(RtLight));
+    std::memcpy(base + hd.offSceneNodes, d->nodes, (size_t)d->nodeCnt * sizeof(RtLinearNode));
+    DevShape* shapes = reinterpret_cast<DevShape*>(base + hd.offShapes);
+    for (int si = 0; si < d->shapeCnt; ++si) {
+        const RtShape& s = d->shapes[si];
+        DevShape& o = shapes[si];
+        if (s.kind != RT_SHAPE_SPHERE && s.kind != RT_SHAPE_MESH) return bad("shape kind not set");
+        if (s.kind == RT_SHAPE_MESH && (s.meshIdx < 0 || s.meshIdx >= d->meshCnt)) return bad("shape mesh index out of range");
+        o.kind = s.kind;
+        std::memcpy(o.center, s.center, sizeof o.center);
+        o.radius2 = s.radius2;
+        o.meshIdx = s.kind == RT_SHAPE_MESH ? s.meshIdx : -1;
+        o.tag = s.tag;
+        o.materialType = s.material.materialType;
+        o.ior = s.material.ior;
+        o.Ks = s.material.Ks;
+        o.specularExponent = s.material.specularExponent;
+        std::memcpy(o.diffuseColor, s.material.diffuseColor, sizeof o.diffuseColor);
+        if (o.materialType != RT_MAT_DIFFUSE_AND_GLOSSY) hd.hasSecondary = 1;
+    }
+    for (int mi = 0; mi < d->meshCnt; ++mi) {
+        const RtMesh& m = d->meshes[mi];
+        const DevMesh& dm = meshes[mi];
+        std::memcpy(base + dm.offNodes, m.nodes, (size_t)m.nodeCnt * sizeof(RtLinearNode));
+        std::memcpy(base + dm.offVertices, m.vertices, (size_t)m.vertexCnt * sizeof(RtVertex));
+        TriRecord* rec = reinterpret_cast<TriRecord*>(base + dm.offTriRecords);
+        for (int t = 0; t < m.triangleCnt; ++t) {
+            const float* p0 = m.vertices[m.triangles[t].i[0]].position;
+            const float* p1 = m.vertices[m.triangles[t].i[1]].position;
+            const float* p2 = m.vertices[m.triangles[t].i[2]].position;
+            for (int k = 0; k < 3; ++k) {
+                rec[t].v0[k] = p0[k];
+                rec[t].e1[k] = p1[k] - p0[k];  // same fp32 subtraction the reference does per test
+                rec[t].e2[k] = p2[k] - p0[k];
+                rec[t].idx[k] = m.triangles[t].i[k];
+            }
+        }
+        const RtTexture* tex[3] = {&m.diffuse, &m.normals, &m.specular};
+        for (int k = 0; k < 3; ++k)
+            std::memcpy(base + dm.offTex[k], tex[k]->data, (size_t)tex[k]->width * tex[k]->height * 4);
+    }
+    if (d->meshCnt) std::memcpy(base + hd.offMeshes, meshes.data(), meshes.size() * sizeof(DevMesh));
+    std::memcpy(base, &hd, sizeof hd);
+    return RT_OK;
+}
+
+int checkHeader(rt_ctx* ctx, const BlobHeader& hd, size_t bytes) {
+    if (hd.magic != RT_BLOB_MAGIC || hd.version != RT_BLOB_VERSION) return fail(ctx, RT_ERR_INVALID, "not a scene blob");
+    if (hd.totalBytes != bytes) return fail(ctx, RT_ERR_INVALID, "scene blob size mismatch");
+    if (hd.sceneDepth + hd.maxMeshDepth > RT_STACK_ENTRIES) return fail(ctx, RT_ERR_LIMIT, "scene blob exceeds the traversal stack");
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+rt_ctx* rt_create(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count < 1) {
+        fail(nullptr, RT_ERR_DEVICE, "no HIP device available (%s)", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return nullptr;
+    }
+    if (device < 0 || device >= count) {
+        fail(nullptr, RT_ERR_INVALID, "device %d out of range (0..%d)", device, count - 1);
+        return nullptr;
+    }
+    rt_ctx* ctx = new rt_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&ctx->tileQueue, 256) != hipSuccess) {
+        fail(nullptr, RT_ERR_DEVICE, "cannot initialise device %d", device);
+        delete ctx;
+        return nullptr;
+    }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fail(nullptr, RT_ERR_DEVICE, "device %d is %s; this library only carries gfx950 code", device, prop.gcnArchName);
+        hipFree(ctx->tileQueue);
+        hipStreamDestroy(ctx->ownStream);
+        delete ctx;
+        return nullptr;
+    }
+    ctx->cuCount = prop.multiProcessorCount;
+    ctx->stream = ctx->ownStream;
+    for (int s = 0; s < 2; ++s)
+        for (int c = 0; c < 2; ++c) ctx->gridBlocks[s][c] = rtk_persistent_blocks(s, c, ctx->cuCount);
+    return ctx;
+}
+
+void rt_destroy(rt_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& l : ctx->launches) {
+        hipEventDestroy(l.start);
+        hipEventDestroy(l.stop);
+    }
+    hipFree(ctx->tileQueue);
+    hipStreamDestroy(ctx->ownStream);
+    delete ctx;
+}
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_createError.c_str(); }
+
+int rt_set_stream(rt_ctx* ctx, void* hipStream) {
+    if (!ctx) return RT_ERR_INVALID;
+    ctx->stream = hipStream ? reinterpret_cast<hipStream_t>(hipStream) : ctx->ownStream;
+    return RT_OK;
+}
+
+int rt_sync(rt_ctx* ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (int r = bind(ctx)) return r;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int rt_scene_pack(rt_ctx* ctx, const RtSceneDesc* desc, void** blob, size_t* bytes) {
+    if (!blob || !bytes) return fail(ctx, RT_ERR_INVALID, "null output argument");
+    std::vector<unsigned char> host;
+    std::string err;
+    int r = packScene(desc, host, &err);
+    if (r != RT_OK) return fail(ctx, r, "%s", err.c_str());
+    void* p = std::malloc(host.size());
+    if (!p) return fail(ctx, RT_ERR_INVALID, "out of host memory");
+    std::memcpy(p, host.data(), host.size());
+    *blob = p;
+    *bytes = host.size();
+    return RT_OK;
+}
+
+void rt_blob_free(void* blob) { std::free(blob); }
+
+rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
+    if (!ctx) return nullptr;
+    std::vector<unsigned char> host;
+    std::string err;
+    int r = packScene(desc, host, &err);
+    if (r != RT_OK) {
+        fail(ctx, r, "%s", err.c_str());
+        return nullptr;
+    }
+    if (bind(ctx)) return nullptr;
+    unsigned char* dev = nullptr;
+    hipError_t e = hipMalloc((void**)&dev, host.size());
+    if (e == hipSuccess) e = hipMemcpy(dev, host.data(), host.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        fail(ctx, RT_ERR_DEVICE, "scene upload (%zu bytes): %s", host.size(), hipGetErrorString(e));
+        if (dev) hipFree(dev);
+        return nullptr;
+    }
+    rt_scene* sc = new rt_scene();
+    sc->ctx = ctx;
+    sc->blob = dev;
+    sc->ownsBlob = true;
+    sc->bytes = host.size();
+    std::memcpy(&sc->header, host.data(), sizeof(BlobHeader));
+    return sc;
+}
+
+rt_scene* rt_scene_adopt_blob(rt_ctx* ctx, const void* devBlob, size_t bytes) {
+    if (!ctx) return nullptr;
+    if (!devBlob || bytes < sizeof(BlobHeader)) {
+        fail(ctx, RT_ERR_INVALID, "null or short scene blob");
+        return nullptr;
+    }
+    if (bind(ctx)) return nullptr;
+    BlobHeader hd;
+    hipError_t e = hipMemcpy(&hd, devBlob, sizeof hd, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        fail(ctx, RT_ERR_DEVICE, "reading blob header: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    if (checkHeader(ctx, hd, bytes) != RT_OK) return nullptr;
+    rt_scene* sc = new rt_scene();
+    sc->ctx = ctx;
+    sc->blob = const_cast<unsigned char*>(static_cast<const unsigned char*>(devBlob));
+    sc->ownsBlob = false;
+    sc->bytes = bytes;
+    sc->header = hd;
+    return sc;
+}
+
+int rt_scene_blob(rt_scene* scene, const void** devBlob, size_t* bytes) {
+    if (!scene || !devBlob || !bytes) return RT_ERR_INVALID;
+    *devBlob = scene->blob;
+    *bytes = scene->bytes;
+    return RT_OK;
+}
+
+int rt_scene_set_lights(rt_scene* scene, const RtLight* lights, int lightCnt) {
+    if (!scene) return RT_ERR_INVALID;
+    rt_ctx* ctx = scene->ctx;
+    if (!lights || lightCnt != scene->header.lightCnt)
+        return fail(ctx, RT_ERR_INVALID, "light count must stay %d", scene->header.lightCnt);
+    if (int r = bind(ctx)) return r;
+    // stream-ordered so that frames already queued keep the lights they were issued with
+    RT_HIP(ctx, hipMemcpyAsync(scene->blob + scene->header.offLights, lights, (size_t)lightCnt * sizeof(RtLight),
+                               hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+void rt_scene_free(rt_scene* scene) {
+    if (!scene) return;
+    if (scene->ownsBlob) {
+        hipSetDevice(scene->ctx->device);
+        hipStreamSynchronize(scene->ctx->stream);
+        hipFree(scene->blob);
+    }
+    delete scene;
+}
+
+int rt_surface_create(rt_ctx* ctx, int width, int height, void** devSurface, size_t* pitch) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (width < 1 || height < 1 || !devSurface || !pitch) return fail(ctx, RT_ERR_INVALID, "bad surface arguments");
+    if (int r = bind(ctx)) return r;
+    const size_t p = alignUp((size_t)width * 16, 256);
+    void* d = nullptr;
+    RT_HIP(ctx, hipMalloc(&d, p * height));
+    RT_HIP(ctx, hipMemset(d, 0x01, p * height));  // the reference fills new surfaces with 0x01 bytes
+    *devSurface = d;
+    *pitch = p;
+    return RT_OK;
+}
+
+int rt_surface_download(rt_ctx* ctx, const void* devSurface, size_t pitch, int width, int height, float* hostRgba) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!devSurface || !hostRgba || pitch < (size_t)width * 16) return fail(ctx, RT_ERR_INVALID, "bad download arguments");
+    if (int r = bind(ctx)) return r;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemcpy2D(hostRgba, (size_t)width * 16, devSurface, pitch, (size_t)width * 16, height, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+void rt_surface_free(rt_ctx* ctx, void* devSurface) { rt_device_free(ctx, devSurface); }
+
+int rt_device_alloc(rt_ctx* ctx, size_t bytes, void** devPtr) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!devPtr || bytes == 0) return fail(ctx, RT_ERR_INVALID, "bad allocation arguments");
+    if (int r = bind(ctx)) return r;
+    void* d = nullptr;
+    RT_HIP(ctx, hipMalloc(&d, bytes));
+    RT_HIP(ctx, hipMemset(d, 0, bytes));
+    *devPtr = d;
+    return RT_OK;
+}
+
+int rt_device_download(rt_ctx* ctx, const void* devPtr, size_t bytes, void* host) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!devPtr || !host) return fail(ctx, RT_ERR_INVALID, "bad download arguments");
+    if (int r = bind(ctx)) return r;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    RT_HIP(ctx, hipMemcpy(host, devPtr, bytes, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_device_zero(rt_ctx* ctx, void* devPtr, size_t bytes) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!devPtr) return fail(ctx, RT_ERR_INVALID, "null pointer");
+    if (int r = bind(ctx)) return r;
+    RT_HIP(ctx, hipMemsetAsync(devPtr, 0, bytes, ctx->stream));
+    return RT_OK;
+}
+
+void rt_device_free(rt_ctx* ctx, void* devPtr) {
+    if (!ctx || !devPtr) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(devPtr);
+}
+
+int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCamera* cam, void* devSurface, size_t pitch,
+              int blockDim, const RtFrameAux* aux) {
+    (void)blockDim;
+    if (!ctx) return RT_ERR_INVALID;
+    if (!scene || scene->ctx != ctx) return fail(ctx, RT_ERR_INVALID, "scene does not belong to this context");
+    if (!opts || !cam || !devSurface) return fail(ctx, RT_ERR_INVALID, "null argument");
+    if (opts->width < 1 || opts->height < 1) return fail(ctx, RT_ERR_INVALID, "bad frame size %dx%d", opts->width, opts->height);
+    if (pitch < (size_t)opts->width * 16 || pitch % 16 != 0 || (reinterpret_cast<uintptr_t>(devSurface) & 15))
+        return fail(ctx, RT_ERR_INVALID, "surface pitch/alignment must hold %d float4 pixels per row, 16-byte aligned", opts->width);
+    if (opts->samples != 1)
+        return fail(ctx, RT_ERR_INVALID, "samples must be 1 (the reference's multi-sample jitter is not reproducible)");
+    if (opts->maxDepth < 0 || opts->maxDepth > RT_MAX_DEPTH)
+        return fail(ctx, RT_ERR_LIMIT, "maxDepth %d outside 0..%d", opts->maxDepth, RT_MAX_DEPTH);
+    const BlobHeader& hd = scene->header;
+    if (!opts->useSceneBvh && hd.maxMeshDepth > RT_STACK_ENTRIES) return fail(ctx, RT_ERR_LIMIT, "mesh BVH too deep");
+
+    RenderParams p;
+    std::memset(&p, 0, sizeof p);
+    p.blob = scene->blob;
+    p.offLights = hd.offLights;
+    p.offShapes = hd.offShapes;
+    p.offSceneNodes = hd.offSceneNodes;
+    p.offMeshes = hd.offMeshes;
+    p.lightCnt = hd.lightCnt;
+    p.shapeCnt = hd.shapeCnt;
+    p.opts = *opts;
+    std::memcpy(p.orig, cam->orig, sizeof p.orig);
+    std::memcpy(p.camera, cam->camera, sizeof p.camera);
+    p.surface = static_cast<unsigned char*>(devSurface);
+    p.pitch = pitch;
+    p.hitKeys = aux ? aux->hitKeys : nullptr;
+    p.counters = aux ? reinterpret_cast<unsigned long long*>(aux->counters) : nullptr;
+    p.tileQueue = ctx->tileQueue;
+    p.tilesX = (opts->width + RT_TILE - 1) / RT_TILE;
+    p.tilesY = (opts->height + RT_TILE - 1) / RT_TILE;
+    const long long tiles = (long long)p.tilesX * p.tilesY;
+    p.tileFirst = aux ? aux->tileFirst : 0;
+    p.tileStride = aux && aux->tileStride > 0 ? aux->tileStride : 1;
+    if (p.tileFirst < 0 || p.tileFirst >= p.tileStride) return fail(ctx, RT_ERR_INVALID, "tileFirst must be in [0, tileStride)");
+    p.tileCnt = (int)((tiles - p.tileFirst + p.tileStride - 1) / p.tileStride);
+    if (p.tileCnt <= 0) return RT_OK;
+
+    if (int r = bind(ctx)) return r;
+    const int secondary = hd.hasSecondary ? 1 : 0;
+    const int count = p.counters ? 1 : 0;
+    const int grid = (int)std::min<long long>(ctx->gridBlocks[secondary][count], p.tileCnt);
+
+    if (ctx->launchesUsed == ctx->launches.size()) {
+        if (ctx->launches.size() >= 65536) return fail(ctx, RT_ERR_LIMIT, "call rt_timing_reset: too many timed launches");
+        TimedLaunch l;
+        RT_HIP(ctx, hipEventCreate(&l.start));
+        RT_HIP(ctx, hipEventCreate(&l.stop));
+        ctx->launches.push_back(l);
+    }
+    TimedLaunch& l = ctx->launches[ctx->launchesUsed];
+    RT_HIP(ctx, hipMemsetAsync(ctx->tileQueue, 0, 256, ctx->stream));
+    RT_HIP(ctx, hipEventRecord(l.start, ctx->stream));
+    hipError_t e = (hipError_t)rtk_launch_render(&p, secondary, count, grid, ctx->stream);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
+    RT_HIP(ctx, hipEventRecord(l.stop, ctx->stream));
+    ctx->launchesUsed++;
+    return RT_OK;
+}
+
+int rt_timing_reset(rt_ctx* ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    ctx->launchesUsed = 0;
+    return RT_OK;
+}
+
+int rt_timing_read(rt_ctx* ctx, double* totalMs, int* launches) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (int r = bind(ctx)) return r;
+    double total = 0;
+    for (size_t i = 0; i < ctx->launchesUsed; ++i) {
+        RT_HIP(ctx, hipEventSynchronize(ctx->launches[i].stop));
+        float ms = 0;
+        RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->launches[i].start, ctx->launches[i].stop));
+        total += ms;
+    }
+    if (totalMs) *totalMs = total;
+    if (launches) *launches = (int)ctx->launchesUsed;
+    return RT_OK;
+}
+
+}  // extern "C"

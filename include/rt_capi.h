@@ -1,0 +1,272 @@
+/*
+ * rt_capi.h - C-ABI of the gfx950 ray-trace library (librt_gfx950.so).
+ *
+ * This is the drop-in boundary for the per-frame render call of the reference
+ * renderer.  The reference exposes one free function per frame plus two RNG
+ * helpers (cudaTracer/main.cuh:7-12):
+ *
+ *     void cudamain(const DeviceOpts&, const Scene&, const void* surface,
+ *                   size_t pitch, int blockDim, unsigned char* rngStates);
+ *     unsigned char* cu_initCurand(int w, int h);  void cu_cleanCurand(...);
+ *
+ * where `Scene` carries raw device pointers that the reference's
+ * GlobalCudaVector members own (cudaTracer/Scene.cuh:12-19,
+ * cudaTracer/GlobalCudaVector.h:42-59).  Here the library owns all device
+ * memory behind opaque handles; the caller hands over host arrays laid out
+ * exactly like the reference's device structs (same field order and sizes),
+ * and no torch / C++ types cross the boundary.
+ *
+ * All entry points return RT_OK (0) or a negative error code and never call
+ * exit(); the message of the last failure on a context is available from
+ * rt_last_error().  (The reference prints and exits: cudaTracer/cudaUtils.h:13-21.)
+ */
+#ifndef RT_CAPI_H
+#define RT_CAPI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)  /* bad argument / malformed scene            */
+#define RT_ERR_DEVICE (-2)   /* a HIP call failed                         */
+#define RT_ERR_LIMIT (-3)    /* scene exceeds a compiled-in kernel limit  */
+
+/* Deepest recursion level the kernel's bounce stack holds (levels 0..maxDepth
+ * are traced, cudaTracer/tracer.cu:16). */
+#define RT_MAX_DEPTH 15
+/* Per-ray traversal stack entries (scene BVH + mesh BVH share one stack).
+ * The reference reserves int[64] per level (cudaTracer/Scene.cuh:36,
+ * cudaTracer/Mesh.cuh:135); a median-split tree over 10 M triangles is 21
+ * levels deep, so 32 covers every balanced tree the host builder emits.  */
+#define RT_STACK_ENTRIES 32
+
+/* ---- plain-data mirrors of the reference's device structs --------------- */
+
+/* cudaTracer/Vertex.cuh:6-13 (56 bytes) */
+typedef struct RtVertex {
+    float normal[3];
+    float tangent[3];
+    float bitangent[3];
+    float texCoord[2];
+    float position[3];
+} RtVertex;
+
+/* cudaTracer/Triangle.cuh:6-7 (12 bytes) */
+typedef struct RtTriangle {
+    int32_t i[3];
+} RtTriangle;
+
+/* cudaTracer/LinearNode.cuh:4-13 (32 bytes).  `offset` is primitivesOffset
+ * for a leaf and secondChildOffset for an interior node; primCnt == 0 marks an
+ * interior node. */
+typedef struct RtLinearNode {
+    float bbmin[3];
+    float bbmax[3];
+    int32_t offset;
+    uint16_t primCnt;
+    uint8_t axis;
+    uint8_t pad;
+} RtLinearNode;
+
+/* cudaTracer/Texture.cuh:6-11.  `data` is RGBA8, row-major, width*height*4
+ * bytes of host memory. */
+enum { RT_TEX_WRAP = 0, RT_TEX_CLAMP = 1 };
+typedef struct RtTexture {
+    int32_t width;
+    int32_t height;
+    const unsigned char* data;
+    int32_t mode;
+} RtTexture;
+
+/* cudaTracer/Material.cuh:6-17 (32 bytes) */
+enum { RT_MAT_DIFFUSE_AND_GLOSSY = 0, RT_MAT_REFLECTION_AND_REFRACTION = 1, RT_MAT_REFLECTION = 2 };
+typedef struct RtMaterial {
+    int32_t materialType;
+    float ior;
+    float Kd, Ks;
+    float diffuseColor[3];
+    float specularExponent;
+} RtMaterial;
+
+/* cudaTracer/Light.cuh:6-17 (28 bytes) */
+typedef struct RtLight {
+    float position[3];
+    float intensity[3];
+    float power;
+} RtLight;
+
+/* cudaTracer/Mesh.cuh:17-26.  `triangles` are in mesh-BVH leaf order
+ * (cudaTracer/CudaMesh.h:60-63); `transformInverse` is row-major, row-vector
+ * convention (cudaTracer/Mat.cuh:127-149). */
+typedef struct RtMesh {
+    int32_t triangleCnt;
+    const RtTriangle* triangles;
+    int32_t vertexCnt;
+    const RtVertex* vertices;
+    RtTexture diffuse;
+    RtTexture normals;
+    RtTexture specular;
+    int32_t nodeCnt;
+    const RtLinearNode* nodes;
+    float transformInverse[16];
+} RtMesh;
+
+/* cudaTracer/Shape.cuh:8-16.  The reference embeds the Mesh by value in a
+ * union; here a mesh shape names its mesh by index into RtSceneDesc.meshes.
+ * `tag` is the shape's index in creation order (before the scene-BVH reorder,
+ * cudaTracer/RayTracer.cpp:72-75); it is what hit keys report. */
+enum { RT_SHAPE_SPHERE = 0, RT_SHAPE_MESH = 1 };
+typedef struct RtShape {
+    int32_t kind;
+    float center[3]; /* sphere (cudaTracer/Sphere.cuh:30-32) */
+    float radius, radius2;
+    int32_t meshIdx; /* mesh */
+    RtMaterial material;
+    float bbmin[3], bbmax[3];
+    int32_t tag;
+} RtShape;
+
+/* cudaTracer/Scene.cuh:12-19 without the camera (passed per frame).  `shapes`
+ * are in scene-BVH leaf order; `nodes` is the scene BVH. */
+typedef struct RtSceneDesc {
+    const RtLight* lights;
+    int32_t lightCnt;
+    const RtShape* shapes;
+    int32_t shapeCnt;
+    const RtMesh* meshes;
+    int32_t meshCnt;
+    const RtLinearNode* nodes;
+    int32_t nodeCnt;
+} RtSceneDesc;
+
+/* cudaTracer/Options.cuh:23-36, field for field (48 bytes). */
+typedef struct RtDeviceOpts {
+    float imageAspectRatio;
+    float scale;
+    int32_t width;
+    int32_t height;
+    float backgroundColor[3];
+    float shadowBias;
+    int32_t blockSize;
+    int32_t maxDepth;
+    int32_t samples;
+    uint8_t gammaCorrection;
+    uint8_t useSceneBvh;
+    uint8_t useMeshBvhs;
+    uint8_t pad_;
+} RtDeviceOpts;
+
+/* Per-frame camera: Scene::orig and Scene::camera (cudaTracer/Scene.cuh:17-18),
+ * filled by the caller as in cudaTracer/RayTracer.cpp:201-202. */
+typedef struct RtCamera {
+    float orig[3];
+    float camera[16]; /* inverse view matrix, row-major */
+} RtCamera;
+
+/* Optional per-frame outputs and the screen-tile shard of this call.
+ * All pointers are DEVICE pointers (or NULL).
+ *   hitKeys  : width*height * 4 int32 {shape tag, i0, i1, i2} of the primary
+ *              hit (sphere: i = -1; miss: all -1).
+ *   counters : RT_COUNTER_CNT uint64 totals, ADDED to by the call.
+ *   tileFirst/tileStride : the call renders 8x8-pixel tiles t = tileFirst,
+ *              tileFirst+tileStride, ... in row-major tile order; 0/1 = whole
+ *              frame.  Pixels of other tiles are left untouched.            */
+enum {
+    RT_CNT_PRIMARY = 0,   /* primary rays                                    */
+    RT_CNT_SHADOW = 1,    /* shadow rays (diffuse hits x lights, any depth)  */
+    RT_CNT_SECONDARY = 2, /* reflection + refraction rays                    */
+    RT_CNT_NODE = 3,      /* BVH node box tests (both levels)                */
+    RT_CNT_TRI = 4,       /* ray/triangle tests                              */
+    RT_CNT_SPHERE = 5,    /* ray/sphere tests                                */
+    RT_CNT_MESH_ENTRY = 6,/* ray -> object-space transforms                  */
+    RT_CNT_SHADE_MESH = 7,/* shaded mesh hits                                */
+    RT_CNT_SHADE_SPHERE = 8,
+    RT_COUNTER_CNT = 16
+};
+typedef struct RtFrameAux {
+    int32_t* hitKeys;
+    uint64_t* counters;
+    int32_t tileFirst;
+    int32_t tileStride;
+} RtFrameAux;
+
+typedef struct rt_ctx rt_ctx;
+typedef struct rt_scene rt_scene;
+
+/* ---- context -------------------------------------------------------------
+ * One context per GPU and per host thread.  Replaces the implicit CUDA
+ * context + `__device__` globals of cudaTracer/Main.cu:11-13.  `device` is the
+ * HIP device ordinal. */
+rt_ctx* rt_create(int device);
+void rt_destroy(rt_ctx* ctx);
+const char* rt_last_error(const rt_ctx* ctx); /* ctx == NULL: error of the last failed rt_create */
+/* Launch on a caller-owned hipStream_t instead of the context's own stream
+ * (NULL restores the own stream). */
+int rt_set_stream(rt_ctx* ctx, void* hipStream);
+/* Blocks until everything the context enqueued has finished
+ * (cudaDeviceSynchronize at cudaTracer/Main.cu:40). */
+int rt_sync(rt_ctx* ctx);
+
+/* ---- scene upload --------------------------------------------------------
+ * rt_scene_upload replaces the GlobalCudaVector::copyToDevice calls that fill
+ * Scene's device pointers (cudaTracer/RayTracer.cpp:72-77,196-203,
+ * cudaTracer/CudaMesh.h:49-83).  The scene is flattened into one relocatable
+ * blob (index-based tables, 32-byte nodes, 48-byte triangle records); the blob
+ * can also be produced on one GPU, copied device-to-device (e.g. an RCCL
+ * broadcast) and adopted on another with rt_scene_adopt_blob. */
+rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc);
+/* Host-side flattening only: *blob is malloc'ed (free with rt_blob_free). */
+int rt_scene_pack(rt_ctx* ctx, const RtSceneDesc* desc, void** blob, size_t* bytes);
+void rt_blob_free(void* blob);
+/* Adopt a blob that already sits in device memory of ctx's GPU.  The scene
+ * does not take ownership of `devBlob`, which must outlive it. */
+rt_scene* rt_scene_adopt_blob(rt_ctx* ctx, const void* devBlob, size_t bytes);
+/* Device address / size of an uploaded scene's blob (source of a broadcast). */
+int rt_scene_blob(rt_scene* scene, const void** devBlob, size_t* bytes);
+/* Re-upload the light table (same count): RayTracer::updateLights,
+ * cudaTracer/RayTracer.cpp:259-267. */
+int rt_scene_set_lights(rt_scene* scene, const RtLight* lights, int lightCnt);
+void rt_scene_free(rt_scene* scene);
+
+/* ---- surface -------------------------------------------------------------
+ * Pitched float-RGBA frame buffer: cudaMallocPitch in
+ * cudaTracer/TextureRenderer.cpp:222-227 and the pitched->tight read-back of
+ * cudaTracer/TextureRenderer.cpp:86-95. */
+int rt_surface_create(rt_ctx* ctx, int width, int height, void** devSurface, size_t* pitch);
+int rt_surface_download(rt_ctx* ctx, const void* devSurface, size_t pitch, int width, int height,
+                        float* hostRgba);
+void rt_surface_free(rt_ctx* ctx, void* devSurface);
+/* Plain device scratch for RtFrameAux buffers (zero-filled). */
+int rt_device_alloc(rt_ctx* ctx, size_t bytes, void** devPtr);
+int rt_device_download(rt_ctx* ctx, const void* devPtr, size_t bytes, void* host);
+int rt_device_zero(rt_ctx* ctx, void* devPtr, size_t bytes);
+void rt_device_free(rt_ctx* ctx, void* devPtr);
+
+/* ---- the per-frame call --------------------------------------------------
+ * cudamain (cudaTracer/Main.cu:21-41): renders opts->width x opts->height
+ * pixels into `devSurface` (row stride `pitch` bytes, 4 floats per pixel,
+ * alpha = 1).  `blockDim` is accepted for signature parity and ignored: the
+ * kernel runs persistent 64-lane wavefronts over 8x8-pixel tiles.  The call
+ * enqueues on the context's stream and returns; rt_sync waits.  `aux` may be
+ * NULL.  Parity with the reference is defined for samples == 1 (its jitter
+ * RNG, cudaTracer/Main.cu:108-110, is not reproducible); samples > 1 is
+ * rejected. */
+int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCamera* cam,
+              void* devSurface, size_t pitch, int blockDim, const RtFrameAux* aux);
+
+/* HIP-event timing of the render kernel launches since the last reset, on the
+ * stream they ran on.  Call after rt_sync. */
+int rt_timing_reset(rt_ctx* ctx);
+int rt_timing_read(rt_ctx* ctx, double* totalMs, int* launches);
+
+/* cu_initCurand / cu_cleanCurand (cudaTracer/Main.cu:113-150) have no
+ * counterpart: samples == 1 draws no random numbers. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_CAPI_H */
