@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for the bench kernel on one MI355X:
+#   1. kernel trace + stats (per-kernel average duration)
+#   2..n  one --pmc pass each (SQ issue/wait mix, L2 hit/miss, HBM fetch, HBM write)
+# Usage: profiles/run_profile.sh <tag> [bench args...]   (run from the repo root on the GPU box)
+set -u
+TAG=${1:-r01}; shift || true
+OUT=gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+ARGS="--steps 5 --warmup 1 --no-cpu $*"
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$OUT/trace.log"; exit 1; }
+pass() {
+  name=$1; shift
+  timeout -s KILL 300 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS > "$OUT/$name.log" 2>&1 || { echo "pmc pass $name failed"; tail -5 "$OUT/$name.log"; exit 1; }
+}
+pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
+pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_FLAT
+pass l2 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum
+pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
+echo done
