@@ -104,6 +104,8 @@ C_ABI = {
                             C.c_int, C.POINTER(RtFrameAux)]),
     "rt_timing_reset": (C.c_int, [C.c_void_p]),
     "rt_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "rt_timing_read_stages": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "rt_set_path_budget": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 HARNESS = {

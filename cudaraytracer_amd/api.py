@@ -205,6 +205,16 @@ class Context:
         self._check(self.lib.rt_timing_read(self.ctx, C.byref(ms), C.byref(n)), "rt_timing_read")
         return ms.value, n.value
 
+    def timing_read_stages(self):
+        """(total ms, [primary trace, shade, shadow trace, rest] ms, launches) since the last reset."""
+        ms, n = C.c_double(), C.c_int()
+        st = (C.c_double * 4)()
+        self._check(self.lib.rt_timing_read_stages(self.ctx, C.byref(ms), st, C.byref(n)), "rt_timing_read_stages")
+        return ms.value, list(st), n.value
+
+    def set_path_budget(self, nodes_per_pixel):
+        self._check(self.lib.rt_set_path_budget(self.ctx, nodes_per_pixel), "rt_set_path_budget")
+
     def render_frame(self, host_scene, scene=None, want_keys=False, want_counters=False):
         """Convenience: full frame of a HostScene -> (rgba[h,w,4], keys or None, counters dict or None)."""
         own = scene is None

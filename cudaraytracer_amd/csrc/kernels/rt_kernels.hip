@@ -1,17 +1,27 @@
-// rt_kernels.hip - gfx950 render kernel: one 64-lane wavefront per 8x8-pixel
-// tile, persistent wavefronts pulling tiles from an atomic queue, two-level BVH
-// traversal with a per-lane stack in LDS, shading and shadow / bounce rays in
-// the same launch.
+// rt_kernels.hip - gfx950 render kernels.
+//
+// Structure: a frame is a short sequence of launches over "path nodes" (one
+// node = one invocation of the reference's recursive castRay):
+//
+//   traceKernel<closest>  persistent 64-lane wavefronts; every LANE owns one ray
+//                         and pulls the next one from an atomic work queue as
+//                         soon as its ray ends (wave-level chunks of the queue
+//                         keep neighbouring pixels in one wave); two-level BVH
+//                         walk with the per-lane stack in LDS
+//   shadeKernel           hit -> surface (st, normal, textures) -> either a
+//                         shading context + shadow work, or child rays
+//                         (ballot-compacted into the next level's queue)
+//   traceKernel<any hit>  shadow rays: (diffuse hit, light) pairs, ray rebuilt
+//                         from the shading context
+//   accumKernel           Blinn-Phong sum over the lights in light order
+//   resolveKernel         mirror / glass nodes combined bottom-up
+//   finalizeKernel        sample average, gamma, float4 store
 //
 // Arithmetic contract: every fp32 operation below is written in the operation
 // order of the reference's device code (cited per function) and this file is
 // compiled with -ffp-contract=off, IEEE division and square root, denormals on,
 // so hit decisions are bit-identical to a host evaluation of the same formulas.
 // Only powf (gamma, Blinn-Phong) may differ in the last ulp.
-//
-// Data layout (rt_device_format.h): 32-byte nodes fetched as two 16-byte loads,
-// 48-byte triangle records {v0, e1, e2, indices} fetched as three, 64-byte
-// shapes, all inside one blob addressed by offsets.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -20,7 +30,10 @@
 namespace {
 
 constexpr int kWave = 64;
-constexpr int kMaxFrames = RT_MAX_DEPTH + 1;
+constexpr unsigned kChunk = 256;  // rays a wavefront takes from the global queue per atomic
+#ifndef RT_REFILL_LANES
+#define RT_REFILL_LANES 16  // a wavefront refills once this many lanes have finished their rays
+#endif
 
 struct V3 {
     float x, y, z;
@@ -30,6 +43,8 @@ struct V2 {
 };
 
 __device__ __forceinline__ V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 mk(const float* p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 mk(float4 v) { return V3{v.x, v.y, v.z}; }
 __device__ __forceinline__ V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
 __device__ __forceinline__ V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
 __device__ __forceinline__ V3 mul(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
@@ -57,21 +72,20 @@ __device__ __forceinline__ V3 normalized(V3 a) {
 // cudaTracer/Vec.cuh:249-251: I - (N*2)*dot(I,N)
 __device__ __forceinline__ V3 reflect(V3 I, V3 N) { return sub(I, muls(muls(N, 2.0f), dot(I, N))); }
 
-struct Counters {
-    unsigned int c[RT_COUNTER_CNT];
-};
-
-struct Hit {
-    int shape;  // slot in the shape table
-    int tri;    // triangle record of the last accepted triangle
-    float u, v;
-};
+__device__ __forceinline__ unsigned laneRank(unsigned long long mask) {
+    // number of set bits of `mask` below this lane
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
 
 // ---------------------------------------------------------------------------
-// cudaTracer/BoundingBox.cuh:115-139.  n0 = {min.x, min.y, min.z, max.x},
-// n1 = {max.y, max.z, offset, meta}.  1 + 2*gamma(3) == 1 + 3*2^-23 in fp32.
-__device__ __forceinline__ bool boxHit(const float4 n0, const float4 n1, const V3 o, const V3 inv, const bool nx,
-                                       const bool ny, const bool nz, const float rayTMax) {
+// cudaTracer/BoundingBox.cuh:115-139, split in two: everything that does not
+// depend on the ray's current reach (slab overlap and "far plane in front of the
+// origin") is returned as the function value, the entry distance as tMinOut;
+// the node is visited iff  result && tMinOut < ray.tMax  - the reference's final
+// expression.  n0 = {min.x, min.y, min.z, max.x}, n1 = {max.y, max.z, ref, -}.
+// 1 + 2*gamma(3) == 1 + 3*2^-23 in fp32.
+__device__ __forceinline__ bool boxSlabs(const float4 n0, const float4 n1, const V3 o, const V3 inv, const bool nx,
+                                         const bool ny, const bool nz, float& tMinOut) {
     constexpr float kPad = 0x1.000006p+0f;
     float tMin = ((nx ? n0.w : n0.x) - o.x) * inv.x;
     float tMax = ((nx ? n0.x : n0.w) - o.x) * inv.x;
@@ -79,15 +93,16 @@ __device__ __forceinline__ bool boxHit(const float4 n0, const float4 n1, const V
     float tyMax = ((ny ? n0.y : n1.x) - o.y) * inv.y;
     tMax *= kPad;
     tyMax *= kPad;
-    if (tMin > tyMax || tyMin > tMax) return false;
+    bool ok = !(tMin > tyMax || tyMin > tMax);
     if (tyMin > tMin) tMin = tyMin;
     if (tyMax < tMax) tMax = tyMax;
     const float tzMin = ((nz ? n1.y : n0.z) - o.z) * inv.z;
     const float tzMax = ((nz ? n0.z : n1.y) - o.z) * inv.z;
-    if (tMin > tzMax || tzMin > tMax) return false;
+    ok = ok && !(tMin > tzMax || tzMin > tMax);
     if (tzMin > tMin) tMin = tzMin;
     if (tzMax < tMax) tMax = tzMax;
-    return (tMin < rayTMax) && (tMax > 0);
+    tMinOut = tMin;
+    return ok && (tMax > 0);
 }
 
 // cudaTracer/Mesh.cuh:182-212 on a precomputed {v0, e1, e2} record.
@@ -116,7 +131,7 @@ __device__ __forceinline__ bool triangleHit(const float4 r0, const float4 r1, co
 
 // cudaTracer/Sphere.cuh:9-54
 __device__ __forceinline__ bool sphereHit(const DevShape& s, const V3 o, const V3 d, float& tMax) {
-    const V3 L = sub(o, mk(s.center[0], s.center[1], s.center[2]));
+    const V3 L = sub(o, mk(s.center));
     const float a = dot(d, d);
     const float b = 2.0f * dot(d, L);
     const float c = dot(L, L) - s.radius2;
@@ -143,163 +158,410 @@ __device__ __forceinline__ bool sphereHit(const DevShape& s, const V3 o, const V
     return true;
 }
 
+// cudaTracer/tracer.cu:202-215
+__device__ __forceinline__ V3 biasedOrigin(V3 dir, V3 P, V3 n, float bias) {
+    return dot(dir, n) < 0.0f ? add(P, muls(n, bias)) : sub(P, muls(n, bias));
+}
+__device__ __forceinline__ V3 invBiasedOrigin(V3 dir, V3 P, V3 n, float bias) {
+    return dot(dir, n) < 0.0f ? sub(P, muls(n, bias)) : add(P, muls(n, bias));
+}
+
 // ---------------------------------------------------------------------------
-// Mesh BVH walk (cudaTracer/Mesh.cuh:115-179).  `stk` is this lane's column of
-// the LDS stack, already advanced past the scene-level entries.
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool meshHit(const RenderParams& P, const DevMesh* __restrict__ m, const V3 wo, const V3 wd,
-                                        float& tMax, Hit& h, int* stk, Counters& cnt) {
-    const float4* M = reinterpret_cast<const float4*>(m->inv);
-    const float4 m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
-    // cudaTracer/Mat.cuh:127-149: row vector * matrix; the point is divided by w,
-    // the direction is neither translated nor renormalised, so t is shared.
-    const float pa = ((wo.x * m0.x + wo.y * m1.x) + wo.z * m2.x) + m3.x;
-    const float pb = ((wo.x * m0.y + wo.y * m1.y) + wo.z * m2.y) + m3.y;
-    const float pc = ((wo.x * m0.z + wo.y * m1.z) + wo.z * m2.z) + m3.z;
-    const float pw = ((wo.x * m0.w + wo.y * m1.w) + wo.z * m2.w) + m3.w;
-    const V3 o = mk(pa / pw, pb / pw, pc / pw);
-    const V3 d = mk((wd.x * m0.x + wd.y * m1.x) + wd.z * m2.x, (wd.x * m0.y + wd.y * m1.y) + wd.z * m2.y,
-                    (wd.x * m0.z + wd.y * m1.z) + wd.z * m2.z);
-    if (COUNT) cnt.c[RT_CNT_MESH_ENTRY]++;
-    const float4* tris = reinterpret_cast<const float4*>(P.blob + m->offTriRecords);
-    bool hit = false;
-    float t = tMax;
-    if (P.opts.useMeshBvhs) {
-        const float4* nodes = reinterpret_cast<const float4*>(P.blob + m->offNodes);
-        const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        const bool nx = inv.x < 0, ny = inv.y < 0, nz = inv.z < 0;
-        int sp = 0;
-        int cur = 0;
-        while (true) {
-            const float4 n0 = nodes[2 * cur];
-            const float4 n1 = nodes[2 * cur + 1];
-            if (COUNT) cnt.c[RT_CNT_NODE]++;
-            if (boxHit(n0, n1, o, inv, nx, ny, nz, t)) {
-                const unsigned meta = __float_as_uint(n1.w);
-                const int off = __float_as_int(n1.z);
-                const int primCnt = (int)(meta & 0xffffu);
-                if (primCnt > 0) {
-                    for (int i = 0; i < primCnt; ++i) {
-                        const float4* r = tris + 3 * (size_t)(off + i);
-                        const float4 r0 = r[0];
-                        const float4 r1 = r[1];
-                        const float e2z = reinterpret_cast<const float*>(r + 2)[0];
-                        if (COUNT) cnt.c[RT_CNT_TRI]++;
-                        if (triangleHit(r0, r1, e2z, o, d, t, h.u, h.v)) {
-                            h.tri = off + i;
-                            hit = true;
-                            if (ANY) {
-                                tMax = t;
-                                return true;
-                            }
-                        }
-                    }
-                    if (sp == 0) break;
-                    cur = stk[(--sp) * kWave];
-                } else {
-                    const unsigned axis = (meta >> 16) & 0xffu;
-                    const bool negAxis = axis == 0 ? nx : (axis == 1 ? ny : nz);
-                    if (negAxis) {
-                        stk[sp * kWave] = cur + 1;
-                        cur = off;
-                    } else {
-                        stk[sp * kWave] = off;
-                        cur = cur + 1;
-                    }
-                    ++sp;
-                }
-            } else {
-                if (sp == 0) break;
-                cur = stk[(--sp) * kWave];
-            }
-        }
-    } else {
-        for (int i = 0; i < m->triangleCnt; ++i) {
-            const float4* r = tris + 3 * (size_t)i;
-            if (COUNT) cnt.c[RT_CNT_TRI]++;
-            if (triangleHit(r[0], r[1], reinterpret_cast<const float*>(r + 2)[0], o, d, t, h.u, h.v)) {
-                h.tri = i;
-                hit = true;
-                if (ANY) break;
-            }
-        }
-    }
-    tMax = t;
-    return hit;
+// Level-0 node -> pixel.  Node s of this call is lane (s & 63) of local tile
+// s >> 6; local tile k is frame tile tileFirst + k * tileStride (row-major).
+__device__ __forceinline__ bool slotPixel(const FrameParams& P, int slot, int& x, int& y) {
+    const int tile = P.tileFirst + (slot >> 6) * P.tileStride;
+    const int l = slot & 63;
+    x = (tile % P.tilesX) * RT_TILE + (l & (RT_TILE - 1));
+    y = (tile / P.tilesX) * RT_TILE + (l >> 3);
+    return x < P.opts.width && y < P.opts.height;
 }
 
-// cudaTracer/Shape.cuh:81-87
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool shapeHit(const RenderParams& P, const DevShape* __restrict__ shapes, const int slot,
-                                         const V3 o, const V3 d, float& tMax, Hit& h, int* stk, Counters& cnt) {
-    const DevShape& s = shapes[slot];
-    if (s.kind == RT_SHAPE_SPHERE) {
-        if (COUNT) cnt.c[RT_CNT_SPHERE]++;
-        return sphereHit(s, o, d, tMax);
-    }
-    const DevMesh* m = reinterpret_cast<const DevMesh*>(P.blob + P.offMeshes) + s.meshIdx;
-    return meshHit<ANY, COUNT>(P, m, o, d, tMax, h, stk, cnt);
+// Primary ray direction, cudaTracer/Main.cu:57-75 with samples == 1 (both jitters are exactly 0.0f).
+__device__ __forceinline__ V3 primaryDir(const FrameParams& P, int x, int y) {
+    const float widthScale = 1.0f / (float)P.opts.width;
+    const float heightScale = 1.0f / (float)P.opts.height;
+    const float ndcX = (2.0f * ((float)x + 0.5f) * widthScale - 1.0f) * P.opts.imageAspectRatio * P.opts.scale;
+    const float ndcY = (1.0f - 2.0f * ((float)y + 0.5f) * heightScale) * P.opts.scale;
+    V3 dir = normalized(mk(ndcX + 0.0f * widthScale, ndcY + 0.0f * heightScale, 1.0f));
+    const float* C = P.camera;
+    dir = mk((dir.x * C[0] + dir.y * C[4]) + dir.z * C[8], (dir.x * C[1] + dir.y * C[5]) + dir.z * C[9],
+             (dir.x * C[2] + dir.y * C[6]) + dir.z * C[10]);
+    return normalized(dir);
 }
 
-// Scene-level walk (cudaTracer/Scene.cuh:21-87).  With ANY the walk ends at the
-// first accepted primitive: the boolean is the same as the full walk's, because
-// acceptance of that primitive does not depend on what is tested after it.
+// Ray of a path node: level 0 is rebuilt from the pixel, deeper nodes are stored.
+__device__ __forceinline__ void nodeRay(const FrameParams& P, int node, V3& o, V3& d) {
+    if (node < P.slots) {
+        int x, y;
+        slotPixel(P, node, x, y);
+        o = mk(P.orig);
+        d = primaryDir(P, x, y);
+    } else {
+        const float4* r = P.secRay + 2 * (size_t)(node - P.slots);
+        o = mk(r[0]);
+        d = mk(r[1]);
+    }
+}
+
+// Shadow ray of (diffuse hit k, light i), cudaTracer/tracer.cu:175-183: origin
+// biased along the normal by the sign of view . n, direction and reach taken
+// from the UNBIASED hit point.
+__device__ __forceinline__ void shadowRay(const FrameParams& P, unsigned k, int light, V3& o, V3& d, float& tMax) {
+    const float4* c = P.ctx + 4 * (size_t)k;
+    const float4 c0 = c[0], c1 = c[1], c2 = c[2];
+    const V3 hitPoint = mk(c0.x, c0.y, c0.z);
+    const V3 n = mk(c0.w, c1.x, c1.y);
+    const V3 view = mk(c1.z, c1.w, c2.x);
+    const RtLight* L = reinterpret_cast<const RtLight*>(P.blob + P.offLights) + light;
+    V3 lightDir = sub(mk(L->position), hitPoint);
+    tMax = magnitude(lightDir);
+    d = normalized(lightDir);
+    o = biasedOrigin(view, hitPoint, n, P.opts.shadowBias);
+}
+
+enum { MODE_NODE = 0, MODE_TRI = 1, MODE_SHAPE = 2, MODE_POP = 3, MODE_DONE = 4 };
+
+// ---------------------------------------------------------------------------
+// Persistent traversal kernel.  ANY = false: closest hit for the path nodes of
+// `level` (cudaTracer/Scene.cuh:21-87 + cudaTracer/Mesh.cuh:115-179).  ANY =
+// true: shadow rays of the level's diffuse hits; the walk ends at the first
+// accepted primitive, which yields the same boolean as the reference's full
+// walk because acceptance of that primitive does not depend on later tests.
+//
+// Every LANE owns one ray and runs a small state machine:
+//   NODE   expand an interior node: ONE 64-byte fetch brings both child boxes;
+//          the near child (by the sign of the ray along the split axis) is
+//          tested against the ray's current reach and entered, the far child is
+//          pushed together with its entry distance
+//   POP    take the next far child; it is entered iff its stored entry distance
+//          is still below the ray's reach - the same decision the reference
+//          makes when it tests that box at pop time, since the reach is the
+//          only input of the box test that changes along the walk
+//   TRI    test the triangles of a leaf, two records per step
+//   SHAPE  a scene-BVH leaf: sphere test, or change to the mesh's object space
+// The stack (8 bytes per entry: node reference + entry distance) lives in LDS,
+// one column per lane, shared by the scene BVH and the mesh BVH.  Visiting
+// order, near/far choice and the <=-tie rule are the reference's, so results do
+// not depend on which lane or wavefront a ray lands in.
+//
+// Counting (COUNT): a box test is tallied when the reference would perform it -
+// the near child at once, a far child when popped - so the totals equal the
+// reference walk's even when a shadow ray stops early.  For that, this variant
+// also pushes far children that are already known to fail (marked by an
+// infinite entry distance).
 template <bool ANY, bool COUNT>
-__device__ __forceinline__ bool sceneHit(const RenderParams& P, const V3 o, const V3 d, float& tMax, Hit& h, int* stk,
-                                         Counters& cnt) {
-    const DevShape* shapes = reinterpret_cast<const DevShape*>(P.blob + P.offShapes);
-    bool hit = false;
-    if (P.opts.useSceneBvh) {
-        const float4* nodes = reinterpret_cast<const float4*>(P.blob + P.offSceneNodes);
-        const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-        const bool nx = inv.x < 0, ny = inv.y < 0, nz = inv.z < 0;
-        int sp = 0;
-        int cur = 0;
-        while (true) {
-            const float4 n0 = nodes[2 * cur];
-            const float4 n1 = nodes[2 * cur + 1];
-            if (COUNT) cnt.c[RT_CNT_NODE]++;
-            if (boxHit(n0, n1, o, inv, nx, ny, nz, tMax)) {
-                const unsigned meta = __float_as_uint(n1.w);
-                const int off = __float_as_int(n1.z);
-                const int primCnt = (int)(meta & 0xffffu);
-                if (primCnt > 0) {
-                    for (int i = 0; i < primCnt; ++i) {
-                        if (shapeHit<ANY, COUNT>(P, shapes, off + i, o, d, tMax, h, stk + sp * kWave, cnt)) {
-                            h.shape = off + i;
-                            hit = true;
-                            if (ANY) return true;
-                        }
+__global__ void __launch_bounds__(kWave) traceKernel(const FrameParams P, const int level) {
+    extern __shared__ uint2 s_stack[];
+    const int lane = threadIdx.x;
+    uint2* const stk = s_stack + lane;
+
+    const unsigned total = ANY ? P.ctl[CTL_DIFFUSE_CNT] * (unsigned)P.lightCnt : P.ctl[CTL_LEVEL_COUNT + level];
+    const unsigned first = ANY ? 0u : P.ctl[CTL_LEVEL_START + level];
+    unsigned* const queue = P.ctl + (ANY ? CTL_SHADOW_QUEUE : CTL_TRACE_QUEUE);
+
+    const float4* const sceneNodes = reinterpret_cast<const float4*>(P.blob + P.offSceneNodes);
+    const DevShape* const shapes = reinterpret_cast<const DevShape*>(P.blob + P.offShapes);
+    const DevMesh* const meshes = reinterpret_cast<const DevMesh*>(P.blob + P.offMeshes);
+    const bool useSceneBvh = P.opts.useSceneBvh != 0;
+    const bool useMeshBvhs = P.opts.useMeshBvhs != 0;
+    const float kInf = __builtin_huge_valf();
+
+    unsigned cNode = 0, cTri = 0, cSphere = 0, cMesh = 0, cRays = 0, cPrimary = 0;
+
+    // wave-uniform queue state
+    unsigned chunkNext = 0, chunkEnd = 0;
+    bool exhausted = false;
+
+    // per-lane ray state
+    int item = -1;  // work item (node index or shadow index); -1 = idle
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), inv = mk(0, 0, 0), wo = o, wd = d;
+    bool nx = false, ny = false, nz = false;
+    float tMax = 0.0f;
+    int mode = MODE_DONE;
+    unsigned ref = 0;  // interior node to expand (MODE_NODE)
+    int sp = 0, base = 0;
+    int shapeNext = 0, shapeEnd = 0, curShape = -1;
+    int triNext = 0, triEnd = 0;
+    bool inBlas = false, blasHit = false, hitAny = false;
+    int hShape = -1, hTri = -1;
+    float hu = 0.0f, hv = 0.0f;
+    const float4* nodes = sceneNodes;
+    const float4* tris = nullptr;
+
+    // enter the node described by reference r (its box test has passed)
+#define RT_ENTER(r)                                   \
+    do {                                              \
+        const unsigned r_ = (r);                      \
+        if (RT_REF_IS_LEAF(r_)) {                     \
+            const int f_ = (int)RT_REF_LEAF_FIRST(r_); \
+            const int c_ = (int)RT_REF_LEAF_COUNT(r_); \
+            if (inBlas) {                             \
+                triNext = f_;                         \
+                triEnd = f_ + c_;                     \
+                mode = MODE_TRI;                      \
+            } else {                                  \
+                shapeNext = f_;                       \
+                shapeEnd = f_ + c_;                   \
+                mode = MODE_SHAPE;                    \
+            }                                         \
+        } else {                                      \
+            ref = r_;                                 \
+            mode = MODE_NODE;                         \
+        }                                             \
+    } while (0)
+    // test the root record of the current tree (cudaTracer/Scene.cuh:38-39, cudaTracer/Mesh.cuh:137-138)
+#define RT_ROOT()                                                         \
+    do {                                                                  \
+        const float4 a_ = nodes[0], b_ = nodes[1];                        \
+        float t_;                                                         \
+        if (COUNT) cNode++;                                               \
+        if (boxSlabs(a_, b_, o, inv, nx, ny, nz, t_) && t_ < tMax)        \
+            RT_ENTER(__float_as_uint(b_.z));                              \
+        else                                                              \
+            mode = MODE_POP;                                              \
+    } while (0)
+
+    while (true) {
+        // ---- hand new rays to idle lanes ---------------------------------
+        const unsigned long long idle = __ballot(item < 0);
+        if (idle != 0ull && !exhausted) {
+            const unsigned want = (unsigned)__popcll(idle);
+            const unsigned rank = laneRank(idle);
+            unsigned given = 0;
+            while (given < want) {
+                if (chunkNext == chunkEnd) {
+                    unsigned b = 0;
+                    if (lane == 0) b = atomicAdd(queue, kChunk);
+                    b = __builtin_amdgcn_readfirstlane(b);
+                    if (b >= total) {
+                        exhausted = true;
+                        break;
                     }
-                    if (sp == 0) break;
-                    cur = stk[(--sp) * kWave];
+                    chunkNext = b;
+                    chunkEnd = (total - b < kChunk) ? total : b + kChunk;
+                }
+                const unsigned take = (want - given < chunkEnd - chunkNext) ? want - given : chunkEnd - chunkNext;
+                if (item < 0 && rank >= given && rank < given + take) item = (int)(first + chunkNext + (rank - given));
+                chunkNext += take;
+                given += take;
+            }
+            if (item >= 0 && mode == MODE_DONE) {
+                // ---- start this lane's new ray
+                bool valid = true;
+                if (ANY) {
+                    const unsigned k = (unsigned)item / (unsigned)P.lightCnt;
+                    const int li = (int)((unsigned)item - k * (unsigned)P.lightCnt);
+                    shadowRay(P, k, li, o, d, tMax);
                 } else {
-                    const unsigned axis = (meta >> 16) & 0xffu;
-                    const bool negAxis = axis == 0 ? nx : (axis == 1 ? ny : nz);
-                    if (negAxis) {
-                        stk[sp * kWave] = cur + 1;
-                        cur = off;
-                    } else {
-                        stk[sp * kWave] = off;
-                        cur = cur + 1;
+                    if (item < P.slots) {
+                        int x, y;
+                        valid = slotPixel(P, item, x, y);
+                        if (valid && COUNT) cPrimary++;
                     }
+                    if (valid) {
+                        nodeRay(P, item, o, d);
+                        tMax = 3.402823466e+38f;
+                    }
+                }
+                if (valid) {
+                    if (COUNT) cRays++;
+                    inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    nx = inv.x < 0;
+                    ny = inv.y < 0;
+                    nz = inv.z < 0;
+                    nodes = sceneNodes;
+                    inBlas = false;
+                    blasHit = false;
+                    hitAny = false;
+                    hShape = -1;
+                    hTri = -1;
+                    hu = hv = 0.0f;
+                    sp = 0;
+                    base = 0;
+                    if (useSceneBvh) {
+                        RT_ROOT();
+                    } else {
+                        shapeNext = 0;
+                        shapeEnd = P.shapeCnt;
+                        mode = MODE_SHAPE;
+                    }
+                } else {
+                    // tile pixel outside the frame: no ray, marked so that later stages skip it
+                    P.hit[item] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-2));
+                    item = -1;
+                }
+            }
+        }
+        if (__ballot(item >= 0) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+
+        // ---- advance every active lane until enough lanes have finished -----
+        while (true) {
+            // one fetch per step: the child pair of an interior node, or two triangle records
+            const bool isNode = mode == MODE_NODE, isTri = mode == MODE_TRI;
+            float4 L0, L1, L2, L3, L4;
+            float L5 = 0.0f;
+            L0 = L1 = L2 = L3 = L4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (isNode || isTri) {
+                const float4* p = isNode ? nodes + 2 * (size_t)RT_REF_PAIR(ref) : tris + 3 * (size_t)triNext;
+                L0 = p[0];
+                L1 = p[1];
+                L2 = p[2];
+                L3 = p[3];
+                if (isTri) {
+                    L4 = p[4];
+                    L5 = reinterpret_cast<const float*>(p + 5)[0];
+                }
+            }
+            if (isNode) {
+                float t0, t1;
+                const bool g0 = boxSlabs(L0, L1, o, inv, nx, ny, nz, t0);
+                const bool g1 = boxSlabs(L2, L3, o, inv, nx, ny, nz, t1);
+                const unsigned axis = RT_REF_AXIS(ref);
+                const bool negAxis = axis == 0 ? nx : (axis == 1 ? ny : nz);
+                // cudaTracer/Mesh.cuh:155-161: with a negative direction along the split axis the
+                // second child is nearer; the other one waits on the stack
+                const unsigned nearRef = __float_as_uint(negAxis ? L3.z : L1.z);
+                const unsigned farRef = __float_as_uint(negAxis ? L1.z : L3.z);
+                const bool nearGeo = negAxis ? g1 : g0, farGeo = negAxis ? g0 : g1;
+                const float nearT = negAxis ? t1 : t0, farT = negAxis ? t0 : t1;
+                const bool farHit = farGeo && farT < tMax;
+                if (COUNT || farHit) {
+                    stk[sp * kWave] = make_uint2(farRef, __float_as_uint(farHit ? farT : kInf));
                     ++sp;
                 }
-            } else {
-                if (sp == 0) break;
-                cur = stk[(--sp) * kWave];
+                if (COUNT) cNode++;
+                if (nearGeo && nearT < tMax)
+                    RT_ENTER(nearRef);
+                else
+                    mode = MODE_POP;
             }
+            if (isTri) {
+                // cudaTracer/Mesh.cuh:141-146: leaf triangles in order; a later hit at equal t replaces an earlier one
+                if (COUNT) cTri++;
+                if (triangleHit(L0, L1, L2.x, o, d, tMax, hu, hv)) {
+                    hTri = triNext;
+                    blasHit = true;
+                    if (ANY) hitAny = true;
+                }
+                if (!(ANY && hitAny) && triNext + 1 < triEnd) {
+                    if (COUNT) cTri++;
+                    if (triangleHit(L3, L4, L5, o, d, tMax, hu, hv)) {
+                        hTri = triNext + 1;
+                        blasHit = true;
+                        if (ANY) hitAny = true;
+                    }
+                }
+                triNext += 2;
+                if (ANY && hitAny)
+                    mode = MODE_DONE;
+                else if (triNext >= triEnd)
+                    mode = MODE_POP;
+            }
+            if (mode == MODE_SHAPE) {
+                curShape = shapeNext++;
+                const DevShape& s = shapes[curShape];
+                if (s.kind == RT_SHAPE_SPHERE) {
+                    if (COUNT) cSphere++;
+                    if (sphereHit(s, o, d, tMax)) {
+                        hShape = curShape;
+                        hitAny = true;
+                        if (ANY) mode = MODE_DONE;
+                    }
+                    if (mode != MODE_DONE && shapeNext == shapeEnd) mode = MODE_POP;
+                } else {
+                    // cudaTracer/Mesh.cuh:115-117 + cudaTracer/Mat.cuh:127-149: the origin is
+                    // divided by w, the direction is neither translated nor renormalised
+                    const DevMesh* m = meshes + s.meshIdx;
+                    const float4* M = reinterpret_cast<const float4*>(m->inv);
+                    const float4 m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
+                    if (COUNT) cMesh++;
+                    wo = o;
+                    wd = d;
+                    const float pa = ((wo.x * m0.x + wo.y * m1.x) + wo.z * m2.x) + m3.x;
+                    const float pb = ((wo.x * m0.y + wo.y * m1.y) + wo.z * m2.y) + m3.y;
+                    const float pc = ((wo.x * m0.z + wo.y * m1.z) + wo.z * m2.z) + m3.z;
+                    const float pw = ((wo.x * m0.w + wo.y * m1.w) + wo.z * m2.w) + m3.w;
+                    o = mk(pa / pw, pb / pw, pc / pw);
+                    d = mk((wd.x * m0.x + wd.y * m1.x) + wd.z * m2.x, (wd.x * m0.y + wd.y * m1.y) + wd.z * m2.y,
+                           (wd.x * m0.z + wd.y * m1.z) + wd.z * m2.z);
+                    inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    nx = inv.x < 0;
+                    ny = inv.y < 0;
+                    nz = inv.z < 0;
+                    inBlas = true;
+                    blasHit = false;
+                    base = sp;
+                    nodes = reinterpret_cast<const float4*>(P.blob + m->offNodes);
+                    tris = reinterpret_cast<const float4*>(P.blob + m->offTriRecords);
+                    if (useMeshBvhs) {
+                        RT_ROOT();
+                    } else {
+                        triNext = 0;
+                        triEnd = m->triangleCnt;
+                        mode = MODE_TRI;
+                    }
+                }
+            }
+            while (mode == MODE_POP) {
+                if (sp > base) {
+                    const uint2 e = stk[(--sp) * kWave];
+                    if (COUNT) cNode++;
+                    if (__uint_as_float(e.y) < tMax) RT_ENTER(e.x);
+                } else if (inBlas) {
+                    // mesh walk finished: back to world space (t is shared between the spaces)
+                    inBlas = false;
+                    o = wo;
+                    d = wd;
+                    inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    nx = inv.x < 0;
+                    ny = inv.y < 0;
+                    nz = inv.z < 0;
+                    nodes = sceneNodes;
+                    base = 0;
+                    if (blasHit) {
+                        hShape = curShape;
+                        hitAny = true;
+                    }
+                    if (shapeNext < shapeEnd) mode = MODE_SHAPE;
+                } else {
+                    mode = MODE_DONE;
+                }
+            }
+            // keep going while most lanes still work; once the queue is dry, until all are done
+            const unsigned long long busy = __ballot(item >= 0 && mode != MODE_DONE);
+            if (busy == 0ull) break;
+            if (!exhausted && __popcll(busy) <= kWave - RT_REFILL_LANES && __ballot(item >= 0) != busy) break;
         }
-    } else {
-        for (int i = 0; i < P.shapeCnt; ++i) {
-            if (shapeHit<ANY, COUNT>(P, shapes, i, o, d, tMax, h, stk, cnt)) {
-                h.shape = i;
-                hit = true;
-                if (ANY) break;
+
+        // ---- finished lanes publish their result and become idle ----------
+        if (item >= 0 && mode == MODE_DONE) {
+            if (ANY) {
+                P.vis[item] = hitAny ? 0 : 1;
+            } else {
+                P.hit[item] = make_float4(tMax, hu, hv, __int_as_float(hitAny ? hShape : -1));
+                P.hitTri[item] = hTri;
             }
+            item = -1;
         }
     }
-    return hit;
+#undef RT_ENTER
+#undef RT_ROOT
+
+    if (COUNT && P.counters) {
+        unsigned vals[6] = {cNode, cTri, cSphere, cMesh, cRays, cPrimary};
+        const int where[6] = {RT_CNT_NODE, RT_CNT_TRI, RT_CNT_SPHERE, RT_CNT_MESH_ENTRY,
+                              ANY ? RT_CNT_SHADOW : (level > 0 ? RT_CNT_SECONDARY : -1), ANY ? -1 : RT_CNT_PRIMARY};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            unsigned v = vals[i];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+            if (lane == 0 && v && where[i] >= 0) atomicAdd(P.counters + where[i], (unsigned long long)v);
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -335,7 +597,7 @@ __device__ __forceinline__ V3 texSample(const unsigned char* __restrict__ data, 
     const V3 bot = add(muls(texel(data, w, h, mode, x, y + 1), uo), muls(texel(data, w, h, mode, x + 1, y + 1), ur));
     return add(muls(top, vo), muls(bot, vr));
 }
-__device__ __forceinline__ V3 meshTex(const RenderParams& P, const DevMesh* m, int which, V2 st) {
+__device__ __forceinline__ V3 meshTex(const FrameParams& P, const DevMesh* m, int which, V2 st) {
     return texSample(P.blob + m->offTex[which], m->texW[which], m->texH[which], m->texMode[which], st.x, st.y);
 }
 
@@ -374,290 +636,328 @@ __device__ __forceinline__ V3 refract(V3 I, V3 N, float ior) {
     if (k < 0.0f) return mk(0.0f, 0.0f, 0.0f);
     return add(muls(I, eta), muls(n, eta * cosi - sqrtf(k)));
 }
-// cudaTracer/tracer.cu:202-215
-__device__ __forceinline__ V3 biasedOrigin(V3 dir, V3 P, V3 n, float bias) {
-    return dot(dir, n) < 0.0f ? add(P, muls(n, bias)) : sub(P, muls(n, bias));
-}
-__device__ __forceinline__ V3 invBiasedOrigin(V3 dir, V3 P, V3 n, float bias) {
-    return dot(dir, n) < 0.0f ? sub(P, muls(n, bias)) : add(P, muls(n, bias));
-}
-
-struct Surface {
-    V3 hitPoint;
-    V3 n;
-    V2 st;
-};
 
 // cudaTracer/Mesh.cuh:101-109
 __device__ __forceinline__ float lerp3(float a, float b, float c, float w, float u, float v) { return (a * w + b * u) + c * v; }
 
 // st + normal of a mesh hit (cudaTracer/Mesh.cuh:65-95); the normal stays in object space.
-__device__ __forceinline__ void meshSurface(const RenderParams& P, const DevMesh* m, const Hit& h, Surface& s) {
-    const TriRecord* rec = reinterpret_cast<const TriRecord*>(P.blob + m->offTriRecords) + h.tri;
+__device__ __forceinline__ void meshSurface(const FrameParams& P, const DevMesh* m, const TriRecord* rec, float hu, float hv,
+                                            V2& st, V3& nOut) {
     const RtVertex* verts = reinterpret_cast<const RtVertex*>(P.blob + m->offVertices);
     const RtVertex* a = verts + rec->idx[0];
     const RtVertex* b = verts + rec->idx[1];
     const RtVertex* c = verts + rec->idx[2];
-    const float w = (1.0f - h.u) - h.v;
-    s.st.x = lerp3(a->texCoord[0], b->texCoord[0], c->texCoord[0], w, h.u, h.v);
-    s.st.y = lerp3(a->texCoord[1], b->texCoord[1], c->texCoord[1], w, h.u, h.v);
+    const float w = (1.0f - hu) - hv;
+    st.x = lerp3(a->texCoord[0], b->texCoord[0], c->texCoord[0], w, hu, hv);
+    st.y = lerp3(a->texCoord[1], b->texCoord[1], c->texCoord[1], w, hu, hv);
     V3 t, bt, n;
-    t.x = lerp3(a->tangent[0], b->tangent[0], c->tangent[0], w, h.u, h.v);
-    t.y = lerp3(a->tangent[1], b->tangent[1], c->tangent[1], w, h.u, h.v);
-    t.z = lerp3(a->tangent[2], b->tangent[2], c->tangent[2], w, h.u, h.v);
-    bt.x = lerp3(a->bitangent[0], b->bitangent[0], c->bitangent[0], w, h.u, h.v);
-    bt.y = lerp3(a->bitangent[1], b->bitangent[1], c->bitangent[1], w, h.u, h.v);
-    bt.z = lerp3(a->bitangent[2], b->bitangent[2], c->bitangent[2], w, h.u, h.v);
-    n.x = lerp3(a->normal[0], b->normal[0], c->normal[0], w, h.u, h.v);
-    n.y = lerp3(a->normal[1], b->normal[1], c->normal[1], w, h.u, h.v);
-    n.z = lerp3(a->normal[2], b->normal[2], c->normal[2], w, h.u, h.v);
-    V3 ns = meshTex(P, m, 1, s.st);
+    t.x = lerp3(a->tangent[0], b->tangent[0], c->tangent[0], w, hu, hv);
+    t.y = lerp3(a->tangent[1], b->tangent[1], c->tangent[1], w, hu, hv);
+    t.z = lerp3(a->tangent[2], b->tangent[2], c->tangent[2], w, hu, hv);
+    bt.x = lerp3(a->bitangent[0], b->bitangent[0], c->bitangent[0], w, hu, hv);
+    bt.y = lerp3(a->bitangent[1], b->bitangent[1], c->bitangent[1], w, hu, hv);
+    bt.z = lerp3(a->bitangent[2], b->bitangent[2], c->bitangent[2], w, hu, hv);
+    n.x = lerp3(a->normal[0], b->normal[0], c->normal[0], w, hu, hv);
+    n.y = lerp3(a->normal[1], b->normal[1], c->normal[1], w, hu, hv);
+    n.z = lerp3(a->normal[2], b->normal[2], c->normal[2], w, hu, hv);
+    V3 ns = meshTex(P, m, 1, st);
     ns = mk(ns.x * 2.0f - 1.0f, ns.y * 2.0f - 1.0f, ns.z * 2.0f - 1.0f);
-    s.n = normalized(add(add(n, muls(t, ns.x)), muls(bt, ns.y)));
+    nOut = normalized(add(add(n, muls(t, ns.x)), muls(bt, ns.y)));
 }
 
-// cudaTracer/tracer.cu:169-200 (+ blinnPhong :144-149)
+// ---------------------------------------------------------------------------
+// Shade the nodes of `level`: the body of castRay after trace()
+// (cudaTracer/tracer.cu:22-47).  Diffuse hits leave a shading context and
+// become shadow work; mirror / glass hits spawn their child rays into the next
+// level (slots taken with one atomic per wavefront via ballot compaction), or,
+// at the last level, take the background as the child result exactly as the
+// reference's depth test does (cudaTracer/tracer.cu:16-18).
 template <bool COUNT>
-__device__ __forceinline__ V3 diffuseAndGlossy(const RenderParams& P, const DevShape& shape, const DevMesh* m, const V3 dir,
-                                               const Surface& s, int* stk, Counters& cnt) {
-    const bool isMesh = shape.kind == RT_SHAPE_MESH;
-    const V3 diffuseColor =
-        isMesh ? meshTex(P, m, 0, s.st) : mk(shape.diffuseColor[0], shape.diffuseColor[1], shape.diffuseColor[2]);
-    V3 diffuseLight = mk(0, 0, 0), specularLight = mk(0, 0, 0);
-    const V3 shadowOrig = biasedOrigin(dir, s.hitPoint, s.n, P.opts.shadowBias);
+__global__ void __launch_bounds__(256) shadeKernel(const FrameParams P, const int level) {
+    const unsigned start = P.ctl[CTL_LEVEL_START + level];
+    const unsigned count = P.ctl[CTL_LEVEL_COUNT + level];
+    const unsigned nextStart = start + count;
+    const V3 bg = mk(P.opts.backgroundColor);
+    const DevShape* shapes = reinterpret_cast<const DevShape*>(P.blob + P.offShapes);
+    unsigned cMesh = 0, cSphere = 0;
+    const unsigned stride = gridDim.x * blockDim.x;
+    // every lane of a wave runs the same number of iterations (the ballots below need that)
+    const unsigned rounds = (count + stride - 1) / stride;
+    for (unsigned r = 0; r < rounds; ++r) {
+        const unsigned idx = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool live = idx < count;
+        const int node = (int)(start + (live ? idx : 0));
+        int want = 0;          // child rays this lane needs
+        bool diffuse = false;  // becomes a diffuse hit
+        V3 hitPoint = mk(0, 0, 0), n = mk(0, 0, 0), rd = mk(0, 0, 0), diffuseColor = mk(0, 0, 0);
+        float specMask = 0.0f, specExp = 0.0f, ior = 1.0f;
+        int materialType = -1;
+        if (live) {
+            const float4 h = P.hit[node];
+            const int shapeSlot = __float_as_int(h.w);
+            if (shapeSlot == -2) {
+                // pixel of a partial tile outside the frame
+            } else if (shapeSlot < 0) {
+                P.color[node] = make_float4(bg.x, bg.y, bg.z, 0.0f);
+                P.kind[node] = NODE_DONE;
+                if (level == 0 && P.hitKeys) {
+                    int x, y;
+                    slotPixel(P, node, x, y);
+                    *reinterpret_cast<int4*>(P.hitKeys + ((size_t)y * P.opts.width + x) * 4) = make_int4(-1, -1, -1, -1);
+                }
+            } else {
+                V3 ro;
+                nodeRay(P, node, ro, rd);
+                const DevShape& shape = shapes[shapeSlot];
+                hitPoint = add(ro, muls(rd, h.x));
+                V2 st = V2{1.0f, 1.0f};
+                int4 key = make_int4(shape.tag, -1, -1, -1);
+                const bool isMesh = shape.kind == RT_SHAPE_MESH;
+                const DevMesh* m = reinterpret_cast<const DevMesh*>(P.blob + P.offMeshes) + (isMesh ? shape.meshIdx : 0);
+                if (!isMesh) {
+                    n = normalized(sub(hitPoint, mk(shape.center)));
+                    if (COUNT) cSphere++;
+                } else {
+                    const TriRecord* rec = reinterpret_cast<const TriRecord*>(P.blob + m->offTriRecords) + P.hitTri[node];
+                    meshSurface(P, m, rec, h.y, h.z, st, n);
+                    key.y = rec->idx[0];
+                    key.z = rec->idx[1];
+                    key.w = rec->idx[2];
+                    if (COUNT) cMesh++;
+                }
+                if (level == 0 && P.hitKeys) {
+                    int x, y;
+                    slotPixel(P, node, x, y);
+                    *reinterpret_cast<int4*>(P.hitKeys + ((size_t)y * P.opts.width + x) * 4) = key;
+                }
+                materialType = shape.materialType;
+                ior = shape.ior;
+                if (materialType == RT_MAT_DIFFUSE_AND_GLOSSY) {
+                    diffuse = true;
+                    diffuseColor = isMesh ? meshTex(P, m, 0, st) : mk(shape.diffuseColor);
+                    specMask = isMesh ? meshTex(P, m, 2, st).x : shape.Ks;
+                    specExp = shape.specularExponent;
+                } else if (materialType == RT_MAT_REFLECTION) {
+                    want = 1;
+                } else if (materialType == RT_MAT_REFLECTION_AND_REFRACTION) {
+                    want = 2;
+                } else {
+                    P.color[node] = make_float4(1.0f, 0.5f, 0.25f, 0.0f);
+                    P.kind[node] = NODE_DONE;
+                }
+            }
+        }
+        // ---- diffuse hits: compact into the level's shading-context list
+        const unsigned long long dmask = __ballot(diffuse);
+        if (dmask != 0ull) {
+            unsigned base = 0;
+            if (laneRank(dmask) == 0 && diffuse) base = atomicAdd(P.ctl + CTL_DIFFUSE_CNT, (unsigned)__popcll(dmask));
+            base = __shfl(base, __ffsll((long long)dmask) - 1, kWave);
+            if (diffuse) {
+                const unsigned k = base + laneRank(dmask);
+                float4* c = P.ctx + 4 * (size_t)k;
+                c[0] = make_float4(hitPoint.x, hitPoint.y, hitPoint.z, n.x);
+                c[1] = make_float4(n.y, n.z, rd.x, rd.y);
+                c[2] = make_float4(rd.z, diffuseColor.x, diffuseColor.y, diffuseColor.z);
+                c[3] = make_float4(specMask, specExp, 0.0f, 0.0f);
+                P.ctxNode[k] = node;
+                P.kind[node] = NODE_DONE;
+            }
+        }
+        // ---- mirror / glass hits
+        if (want > 0) {
+            // cudaTracer/tracer.cu:117-142.  Glass reflects the NORMAL about the view direction
+            // (operands swapped with respect to the mirror case), as the reference does.
+            const V3 reflDir = normalized(materialType == RT_MAT_REFLECTION ? reflect(rd, n) : reflect(n, rd));
+            const float kr = fresnel(rd, n, ior);
+            if (level >= P.opts.maxDepth) {
+                // children would be deeper than maxDepth: each returns the background
+                const V3 c = (want == 1) ? muls(bg, kr) : add(muls(bg, kr), muls(bg, 1.0f - kr));
+                P.color[node] = make_float4(c.x, c.y, c.z, 0.0f);
+                P.kind[node] = NODE_DONE;
+                want = 0;
+            } else {
+                P.kr[node] = kr;
+                P.kind[node] = want == 1 ? NODE_MIRROR : NODE_GLASS;
+            }
+            if (want > 0) {
+                // exclusive prefix of `want` over the wave via two ballots (want is 1 or 2)
+                const unsigned long long m1 = __ballot(want >= 1), m2 = __ballot(want == 2);
+                const unsigned totalWant = (unsigned)__popcll(m1) + (unsigned)__popcll(m2);
+                unsigned base = 0;
+                if (laneRank(m1) == 0) base = atomicAdd(P.ctl + CTL_LEVEL_COUNT + level + 1, totalWant);
+                base = __shfl(base, __ffsll((long long)m1) - 1, kWave);
+                const unsigned mine = nextStart + base + laneRank(m1) + laneRank(m2);
+                if (mine + (unsigned)want > (unsigned)P.nodeCap) {
+                    // no room: report, and fall back to the background so that nothing is read out of bounds
+                    atomicOr(P.ctl + CTL_OVERFLOW, 1u);
+                    const V3 c = (want == 1) ? muls(bg, kr) : add(muls(bg, kr), muls(bg, 1.0f - kr));
+                    P.color[node] = make_float4(c.x, c.y, c.z, 0.0f);
+                    P.kind[node] = NODE_DONE;
+                } else {
+                    P.child[node] = (int)mine;
+                    float4* r = P.secRay + 2 * (size_t)(mine - (unsigned)P.slots);
+                    const V3 reflOrig = invBiasedOrigin(reflDir, hitPoint, n, P.opts.shadowBias);
+                    r[0] = make_float4(reflOrig.x, reflOrig.y, reflOrig.z, 0.0f);
+                    r[1] = make_float4(reflDir.x, reflDir.y, reflDir.z, 0.0f);
+                    if (want == 2) {
+                        const V3 refrDir = normalized(refract(rd, n, ior));
+                        const V3 refrOrig = invBiasedOrigin(refrDir, hitPoint, n, P.opts.shadowBias);
+                        r[2] = make_float4(refrOrig.x, refrOrig.y, refrOrig.z, 0.0f);
+                        r[3] = make_float4(refrDir.x, refrDir.y, refrDir.z, 0.0f);
+                    }
+                }
+            }
+        }
+    }
+    if (COUNT && P.counters) {
+        for (int off = 32; off > 0; off >>= 1) {
+            cMesh += __shfl_down(cMesh, off, kWave);
+            cSphere += __shfl_down(cSphere, off, kWave);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (cMesh) atomicAdd(P.counters + RT_CNT_SHADE_MESH, (unsigned long long)cMesh);
+            if (cSphere) atomicAdd(P.counters + RT_CNT_SHADE_SPHERE, (unsigned long long)cSphere);
+        }
+    }
+}
+
+// diffuseAndGlossy (cudaTracer/tracer.cu:169-200, blinnPhong :144-149) for every
+// diffuse hit of the level, lights summed in table order.
+__global__ void __launch_bounds__(256) accumKernel(const FrameParams P) {
+    const unsigned count = P.ctl[CTL_DIFFUSE_CNT];
     const RtLight* lights = reinterpret_cast<const RtLight*>(P.blob + P.offLights);
-    float specMask = 0.0f;
-    bool haveMask = false;
-    for (int i = 0; i < P.lightCnt; ++i) {
-        const RtLight& light = lights[i];
-        V3 lightDir = sub(mk(light.position[0], light.position[1], light.position[2]), s.hitPoint);
-        const float distance = magnitude(lightDir);
-        lightDir = normalized(lightDir);
-        const float lambert = fmaxf(0.f, dot(lightDir, s.n));
-        float tMax = distance;
-        Hit scratch;
-        if (COUNT) cnt.c[RT_CNT_SHADOW]++;
-        const bool visible = !sceneHit<true, COUNT>(P, shadowOrig, lightDir, tMax, scratch, stk, cnt);
-        if (visible) {
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += gridDim.x * blockDim.x) {
+        const float4* c = P.ctx + 4 * (size_t)k;
+        const float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+        const V3 hitPoint = mk(c0.x, c0.y, c0.z);
+        const V3 n = mk(c0.w, c1.x, c1.y);
+        const V3 dir = mk(c1.z, c1.w, c2.x);
+        const V3 diffuseColor = mk(c2.y, c2.z, c2.w);
+        const float specMask = c3.x, specExp = c3.y;
+        V3 diffuseLight = mk(0, 0, 0), specularLight = mk(0, 0, 0);
+        for (int i = 0; i < P.lightCnt; ++i) {
+            if (!P.vis[(size_t)k * P.lightCnt + i]) continue;
+            const RtLight& light = lights[i];
+            V3 lightDir = sub(mk(light.position), hitPoint);
+            const float distance = magnitude(lightDir);
+            lightDir = normalized(lightDir);
+            const float lambert = fmaxf(0.f, dot(lightDir, n));
             float specularFac = 0.0f;
             if (lambert > 0.0f) {
                 const V3 halfDir = normalized(sub(lightDir, dir));
-                const float specAngle = fmaxf(dot(halfDir, s.n), 0.0f);
-                specularFac = powf(specAngle, shape.specularExponent);
+                const float specAngle = fmaxf(dot(halfDir, n), 0.0f);
+                specularFac = powf(specAngle, specExp);
             }
-            if (!haveMask) {  // pure function of st: sampled once, on first use
-                specMask = isMesh ? meshTex(P, m, 2, s.st).x : shape.Ks;
-                haveMask = true;
-            }
-            const V3 lightComponent =
-                divs(muls(mk(light.intensity[0], light.intensity[1], light.intensity[2]), light.power), distance);
+            const V3 lightComponent = divs(muls(mk(light.intensity), light.power), distance);
             diffuseLight = add(diffuseLight, muls(lightComponent, lambert));
             specularLight = add(specularLight, muls(muls(lightComponent, specMask), specularFac));
         }
+        const V3 out = add(mul(diffuseLight, diffuseColor), specularLight);
+        P.color[P.ctxNode[k]] = make_float4(out.x, out.y, out.z, 0.0f);
     }
-    return add(mul(diffuseLight, diffuseColor), specularLight);
 }
 
-// One pending level of the reference's recursion (cudaTracer/tracer.cu:117-142).
-struct Frame {
-    V3 ro, rd;  // refraction ray still to trace (glass)
-    V3 refl;    // colour returned by the reflection child (glass)
-    float kr;
-    int state;
-};
-enum { FRAME_MIRROR = 0, FRAME_GLASS_REFLECTING = 1, FRAME_GLASS_REFRACTING = 2 };
-
-// castRay (cudaTracer/tracer.cu:15-48) with the recursion unrolled into an
-// explicit post-order walk: children are evaluated in the reference's order
-// (reflection first) and combined with the same expressions.
-template <bool SECONDARY, bool COUNT>
-__device__ __forceinline__ V3 castRay(const RenderParams& P, V3 ro, V3 rd, int* stk, Counters& cnt, int* key) {
-    const V3 bg = mk(P.opts.backgroundColor[0], P.opts.backgroundColor[1], P.opts.backgroundColor[2]);
-    const DevShape* shapes = reinterpret_cast<const DevShape*>(P.blob + P.offShapes);
-    Frame frames[SECONDARY ? kMaxFrames : 1];
-    int depth = 0;
-    V3 ret = bg;
-    while (true) {
-        // ---- "call": trace (ro, rd) at `depth`
-        bool spawned = false;
-        if (depth > P.opts.maxDepth) {
-            ret = bg;
+// Combines mirror / glass nodes of `level` with their finished children
+// (cudaTracer/tracer.cu:131,141).
+__global__ void __launch_bounds__(256) resolveKernel(const FrameParams P, const int level) {
+    const unsigned start = P.ctl[CTL_LEVEL_START + level];
+    const unsigned count = P.ctl[CTL_LEVEL_COUNT + level];
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const unsigned node = start + i;
+        if (node < (unsigned)P.slots && __float_as_int(P.hit[node].w) == -2) continue;
+        const int kind = P.kind[node];
+        if (kind == NODE_DONE) continue;
+        const float kr = P.kr[node];
+        const int ch = P.child[node];
+        const V3 refl = mk(P.color[ch]);
+        V3 out;
+        if (kind == NODE_MIRROR) {
+            out = muls(refl, kr);
         } else {
-            if (COUNT && depth > 0) cnt.c[RT_CNT_SECONDARY]++;
-            float tMax = 3.402823466e+38f;
-            Hit h;
-            h.shape = -1;
-            h.tri = -1;
-            h.u = h.v = 0.0f;
-            if (!sceneHit<false, COUNT>(P, ro, rd, tMax, h, stk, cnt)) {
-                ret = bg;
-            } else {
-                const DevShape& shape = shapes[h.shape];
-                const DevMesh* m = reinterpret_cast<const DevMesh*>(P.blob + P.offMeshes) + (shape.kind == RT_SHAPE_MESH ? shape.meshIdx : 0);
-                Surface s;
-                s.hitPoint = add(ro, muls(rd, tMax));
-                if (shape.kind == RT_SHAPE_SPHERE) {
-                    s.st = V2{1.0f, 1.0f};
-                    s.n = normalized(sub(s.hitPoint, mk(shape.center[0], shape.center[1], shape.center[2])));
-                    if (COUNT) cnt.c[RT_CNT_SHADE_SPHERE]++;
-                } else {
-                    meshSurface(P, m, h, s);
-                    if (COUNT) cnt.c[RT_CNT_SHADE_MESH]++;
-                }
-                if (key && depth == 0) {
-                    key[0] = shape.tag;
-                    if (shape.kind == RT_SHAPE_MESH) {
-                        const TriRecord* rec = reinterpret_cast<const TriRecord*>(P.blob + m->offTriRecords) + h.tri;
-                        key[1] = rec->idx[0];
-                        key[2] = rec->idx[1];
-                        key[3] = rec->idx[2];
-                    }
-                }
-                const int mt = shape.materialType;
-                if (mt == RT_MAT_DIFFUSE_AND_GLOSSY) {
-                    ret = diffuseAndGlossy<COUNT>(P, shape, m, rd, s, stk, cnt);
-                } else if (SECONDARY && mt == RT_MAT_REFLECTION) {
-                    const V3 reflDir = normalized(reflect(rd, s.n));
-                    Frame& f = frames[depth];
-                    f.state = FRAME_MIRROR;
-                    f.kr = fresnel(rd, s.n, shape.ior);
-                    ro = invBiasedOrigin(reflDir, s.hitPoint, s.n, P.opts.shadowBias);
-                    rd = reflDir;
-                    spawned = true;
-                } else if (SECONDARY && mt == RT_MAT_REFLECTION_AND_REFRACTION) {
-                    // the reference reflects the NORMAL about the view direction here
-                    const V3 reflDir = normalized(reflect(s.n, rd));
-                    const V3 refrDir = normalized(refract(rd, s.n, shape.ior));
-                    Frame& f = frames[depth];
-                    f.state = FRAME_GLASS_REFLECTING;
-                    f.kr = fresnel(rd, s.n, shape.ior);
-                    f.ro = invBiasedOrigin(refrDir, s.hitPoint, s.n, P.opts.shadowBias);
-                    f.rd = refrDir;
-                    ro = invBiasedOrigin(reflDir, s.hitPoint, s.n, P.opts.shadowBias);
-                    rd = reflDir;
-                    spawned = true;
-                } else {
-                    ret = mk(1.0f, 0.5f, 0.25f);
-                }
-            }
+            const V3 refr = mk(P.color[ch + 1]);
+            out = add(muls(refl, kr), muls(refr, 1.0f - kr));
         }
-        if (SECONDARY && spawned) {
-            ++depth;
-            continue;
-        }
-        // ---- "return": hand `ret` to the pending parents
-        if (!SECONDARY) break;
-        bool resume = false;
-        while (depth > 0) {
-            Frame& f = frames[depth - 1];
-            if (f.state == FRAME_MIRROR) {
-                ret = muls(ret, f.kr);
-                --depth;
-            } else if (f.state == FRAME_GLASS_REFLECTING) {
-                f.refl = ret;
-                f.state = FRAME_GLASS_REFRACTING;
-                ro = f.ro;
-                rd = f.rd;
-                resume = true;  // trace the refraction child at the same depth
-                break;
-            } else {
-                ret = add(muls(f.refl, f.kr), muls(ret, 1.0f - f.kr));
-                --depth;
-            }
-        }
-        if (!resume) break;
+        P.color[node] = make_float4(out.x, out.y, out.z, 0.0f);
     }
-    return ret;
 }
 
-// cudaTracer/Main.cu:43-98 for samples == 1 (both jitters are exactly 0.0f)
-template <bool SECONDARY, bool COUNT>
-__device__ __forceinline__ void renderPixel(const RenderParams& P, int x, int y, int* stk, Counters& cnt) {
-    const float widthScale = 1.0f / (float)P.opts.width;
-    const float heightScale = 1.0f / (float)P.opts.height;
-    const float ndcX = (2.0f * ((float)x + 0.5f) * widthScale - 1.0f) * P.opts.imageAspectRatio * P.opts.scale;
-    const float ndcY = (1.0f - 2.0f * ((float)y + 0.5f) * heightScale) * P.opts.scale;
-    V3 dir = normalized(mk(ndcX + 0.0f * widthScale, ndcY + 0.0f * heightScale, 1.0f));
-    const float* C = P.camera;
-    dir = mk((dir.x * C[0] + dir.y * C[4]) + dir.z * C[8], (dir.x * C[1] + dir.y * C[5]) + dir.z * C[9],
-             (dir.x * C[2] + dir.y * C[6]) + dir.z * C[10]);
-    dir = normalized(dir);
-    int key[4] = {-1, -1, -1, -1};
-    if (COUNT) cnt.c[RT_CNT_PRIMARY]++;
-    V3 col = castRay<SECONDARY, COUNT>(P, mk(P.orig[0], P.orig[1], P.orig[2]), dir, stk, cnt, P.hitKeys ? key : nullptr);
-    col = add(mk(0.0f, 0.0f, 0.0f), col);
-    const float samples = (float)P.opts.samples;
-    col = mk(col.x / samples, col.y / samples, col.z / samples);
-    float4 out;
-    if (P.opts.gammaCorrection) {
-        const float sgInv = 1.0f / 2.2f;
-        out = make_float4(powf(col.x, sgInv), powf(col.y, sgInv), powf(col.z, sgInv), 1.0f);
+// cudaTracer/Main.cu:66-98: sample sum (from 0), average, gamma, store.
+__global__ void __launch_bounds__(256) finalizeKernel(const FrameParams P) {
+    for (unsigned s = blockIdx.x * blockDim.x + threadIdx.x; s < (unsigned)P.slots; s += gridDim.x * blockDim.x) {
+        int x, y;
+        if (!slotPixel(P, (int)s, x, y)) continue;
+        V3 col = add(mk(0.0f, 0.0f, 0.0f), mk(P.color[s]));
+        const float samples = (float)P.opts.samples;
+        col = mk(col.x / samples, col.y / samples, col.z / samples);
+        float4 out;
+        if (P.opts.gammaCorrection) {
+            const float sgInv = 1.0f / 2.2f;
+            out = make_float4(powf(col.x, sgInv), powf(col.y, sgInv), powf(col.z, sgInv), 1.0f);
+        } else {
+            out = make_float4(col.x, col.y, col.z, 1.0f);
+        }
+        *reinterpret_cast<float4*>(P.surface + (size_t)y * P.pitch + (size_t)x * 16) = out;
+    }
+}
+
+// Opens `level`: fixes its first node and clears the per-level queues.
+__global__ void advanceKernel(const FrameParams P, const int level) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (level == 0) {
+        P.ctl[CTL_LEVEL_START] = 0;
+        P.ctl[CTL_LEVEL_COUNT] = (unsigned)P.slots;
     } else {
-        out = make_float4(col.x, col.y, col.z, 1.0f);
+        P.ctl[CTL_LEVEL_START + level] = P.ctl[CTL_LEVEL_START + level - 1] + P.ctl[CTL_LEVEL_COUNT + level - 1];
     }
-    *reinterpret_cast<float4*>(P.surface + (size_t)y * P.pitch + (size_t)x * 16) = out;
-    if (P.hitKeys) {
-        *reinterpret_cast<int4*>(P.hitKeys + ((size_t)y * P.opts.width + x) * 4) = make_int4(key[0], key[1], key[2], key[3]);
-    }
+    P.ctl[CTL_TRACE_QUEUE] = 0;
+    P.ctl[CTL_SHADOW_QUEUE] = 0;
+    P.ctl[CTL_DIFFUSE_CNT] = 0;
 }
 
-template <bool SECONDARY, bool COUNT>
-__global__ void __launch_bounds__(kWave) renderKernel(const RenderParams P) {
-    __shared__ int s_stack[RT_STACK_ENTRIES * kWave];
-    const int lane = threadIdx.x;
-    int* stk = s_stack + lane;
-    Counters cnt;
-    if (COUNT) {
-#pragma unroll
-        for (int i = 0; i < RT_COUNTER_CNT; ++i) cnt.c[i] = 0;
-    }
-    while (true) {
-        // one atomic per wavefront and tile; every wave ends when the queue is drained
-        unsigned int k = 0;
-        if (lane == 0) k = atomicAdd(P.tileQueue, 1u);
-        k = __builtin_amdgcn_readfirstlane(k);
-        if (k >= (unsigned)P.tileCnt) break;
-        const int tile = P.tileFirst + (int)k * P.tileStride;
-        const int tx = tile % P.tilesX;
-        const int ty = tile / P.tilesX;
-        const int x = tx * RT_TILE + (lane & (RT_TILE - 1));
-        const int y = ty * RT_TILE + (lane >> 3);
-        if (x < P.opts.width && y < P.opts.height) renderPixel<SECONDARY, COUNT>(P, x, y, stk, cnt);
-    }
-    if (COUNT && P.counters) {
-#pragma unroll
-        for (int i = 0; i < RT_COUNTER_CNT; ++i) {
-            unsigned int v = cnt.c[i];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
-            if (lane == 0 && v) atomicAdd(P.counters + i, (unsigned long long)v);
-        }
-    }
-}
-
-template <bool S, bool C>
-int launch(const RenderParams* p, int gridBlocks, hipStream_t stream) {
-    hipLaunchKernelGGL((renderKernel<S, C>), dim3(gridBlocks), dim3(kWave), 0, stream, *p);
-    return (int)hipGetLastError();
+template <bool ANY, bool COUNT>
+void launchTrace(const FrameParams& p, int level, int cuCount, hipStream_t s) {
+    const size_t lds = (size_t)p.stackEntries * kWave * sizeof(uint2);
+    int perCu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, traceKernel<ANY, COUNT>, kWave, lds) != hipSuccess || perCu < 1) perCu = 8;
+    if (perCu > 32) perCu = 32;
+    hipLaunchKernelGGL((traceKernel<ANY, COUNT>), dim3(perCu * cuCount), dim3(kWave), lds, s, p, level);
 }
 
 }  // namespace
 
-int rtk_launch_render(const RenderParams* p, int secondary, int count, int gridBlocks, void* stream) {
+int rtk_render_frame(const FrameParams* pp, int hasSecondary, int count, int cuCount, void* stream, void** stageEvents) {
+    const FrameParams& p = *pp;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (secondary) return count ? launch<true, true>(p, gridBlocks, s) : launch<true, false>(p, gridBlocks, s);
-    return count ? launch<false, true>(p, gridBlocks, s) : launch<false, false>(p, gridBlocks, s);
-}
-
-int rtk_persistent_blocks(int secondary, int count, int cuCount) {
-    int perCu = 0;
-    hipError_t e;
-    if (secondary)
-        e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, renderKernel<true, true>, kWave, 0)
-                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, renderKernel<true, false>, kWave, 0);
-    else
-        e = count ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, renderKernel<false, true>, kWave, 0)
-                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, renderKernel<false, false>, kWave, 0);
-    if (e != hipSuccess || perCu < 1) perCu = 8;
-    if (perCu > 32) perCu = 32;
-    return perCu * cuCount;
+    hipEvent_t* ev = reinterpret_cast<hipEvent_t*>(stageEvents);
+    const int lastLevel = hasSecondary ? p.opts.maxDepth : 0;
+    const dim3 wide(cuCount * 8), block(256);
+    hipError_t e = hipMemsetAsync(p.ctl, 0, CTL_WORDS * sizeof(uint32_t), s);
+    if (e != hipSuccess) return (int)e;
+    if (ev) (void)hipEventRecord(ev[0], s);
+    for (int level = 0; level <= lastLevel; ++level) {
+        hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(64), 0, s, p, level);
+        if (count)
+            launchTrace<false, true>(p, level, cuCount, s);
+        else
+            launchTrace<false, false>(p, level, cuCount, s);
+        if (ev && level == 0) (void)hipEventRecord(ev[1], s);
+        if (count)
+            hipLaunchKernelGGL((shadeKernel<true>), wide, block, 0, s, p, level);
+        else
+            hipLaunchKernelGGL((shadeKernel<false>), wide, block, 0, s, p, level);
+        if (ev && level == 0) (void)hipEventRecord(ev[2], s);
+        if (p.lightCnt > 0) {
+            if (count)
+                launchTrace<true, true>(p, level, cuCount, s);
+            else
+                launchTrace<true, false>(p, level, cuCount, s);
+        }
+        if (ev && level == 0) (void)hipEventRecord(ev[3], s);
+        hipLaunchKernelGGL(accumKernel, wide, block, 0, s, p);
+    }
+    for (int level = lastLevel - 1; level >= 0; --level) hipLaunchKernelGGL(resolveKernel, wide, block, 0, s, p, level);
+    hipLaunchKernelGGL(finalizeKernel, wide, block, 0, s, p);
+    if (ev) (void)hipEventRecord(ev[4], s);
+    return (int)hipGetLastError();
 }

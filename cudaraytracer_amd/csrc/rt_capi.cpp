@@ -3,6 +3,7 @@
 // blob (rt_device_format.h), uploads, and the per-frame launch of the render
 // kernel.  Host code only; the kernels live in kernels/rt_kernels.hip.
 #include <hip/hip_runtime_api.h>
+#include <hip/hip_vector_types.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -19,8 +20,28 @@ namespace {
 
 thread_local std::string g_createError;
 
+// Events of one rt_render call: frame start, after the level-0 closest-hit trace,
+// after shading, after the shadow trace, frame end.
 struct TimedLaunch {
-    hipEvent_t start, stop;
+    hipEvent_t ev[5];
+};
+
+// Per-context frame workspace (see FrameParams); grown on demand, never shrunk.
+struct Workspace {
+    int nodeCap = 0;
+    int lightCap = 0;
+    int secCap = 0;
+    void* ctl = nullptr;
+    void* hit = nullptr;
+    void* hitTri = nullptr;
+    void* color = nullptr;
+    void* secRay = nullptr;
+    void* child = nullptr;
+    void* kr = nullptr;
+    void* kind = nullptr;
+    void* ctx = nullptr;
+    void* ctxNode = nullptr;
+    void* vis = nullptr;
 };
 
 }  // namespace
@@ -30,11 +51,11 @@ struct rt_ctx {
     int cuCount = 0;
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
-    unsigned int* tileQueue = nullptr;  // one 256-byte slot, zeroed before every launch
+    Workspace ws;
+    int pathBudget = 3;  // node arrays hold pathBudget x pixels when the scene has mirror / glass materials
     std::string error;
     std::vector<TimedLaunch> launches;  // events of launches since the last reset
     size_t launchesUsed = 0;
-    int gridBlocks[2][2] = {{0, 0}, {0, 0}};
 };
 
 struct rt_scene {
@@ -109,6 +130,48 @@ int treeDepth(const RtLinearNode* nodes, int nodeCnt, int primCnt, int* maxLeafP
     return depth;
 }
 
+// Re-lays a depth-first LinearNode tree out as sibling pairs (see rt_device_format.h).
+// `out` receives 32-byte records {bbmin, bbmax, ref, 0}; its size is 2 * (interior nodes + 1).
+int pairLayout(const RtLinearNode* nodes, std::vector<RtLinearNode>& out, std::string* err) {
+    struct Item {
+        int src, dst;
+    };
+    out.assign(2, RtLinearNode{});
+    std::vector<Item> todo;
+    todo.push_back({0, 0});
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        const RtLinearNode& n = nodes[it.src];
+        RtLinearNode rec = n;
+        uint32_t ref;
+        if (n.primCnt > 0) {
+            if (n.primCnt > RT_REF_MAX_LEAF_PRIMS || n.offset >= RT_REF_MAX_PRIMS) {
+                *err = "BVH leaf too large for the packed node reference (more than 127 primitives in a leaf or 16M primitives)";
+                return RT_ERR_LIMIT;
+            }
+            ref = RT_REF_LEAF | ((uint32_t)n.primCnt << 24) | (uint32_t)n.offset;
+        } else {
+            const size_t pair = out.size();
+            if (pair / 2 >= (1u << 29)) {
+                *err = "BVH too large for the packed node reference";
+                return RT_ERR_LIMIT;
+            }
+            out.resize(pair + 2);
+            ref = ((uint32_t)n.axis << 29) | (uint32_t)(pair >> 1);
+            // second child first on the work stack: the first child's subtree is laid out right behind the pair
+            todo.push_back({n.offset, (int)pair + 1});
+            todo.push_back({it.src + 1, (int)pair});
+        }
+        std::memcpy(&rec.offset, &ref, 4);
+        rec.primCnt = 0;
+        rec.axis = 0;
+        rec.pad = 0;
+        out[it.dst] = rec;
+    }
+    return RT_OK;
+}
+
 // Flattens `desc` into a host blob.  Returns RT_OK or an error (message in *err).
 int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string* err) {
     auto bad = [&](const char* m) {
@@ -143,10 +206,13 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
     };
     hd.offLights = reserve((size_t)std::max(d->lightCnt, 1) * sizeof(RtLight));
     hd.offShapes = reserve((size_t)d->shapeCnt * sizeof(DevShape));
-    hd.offSceneNodes = reserve((size_t)d->nodeCnt * sizeof(RtLinearNode));
+    std::vector<RtLinearNode> scenePairs;
+    if (int r = pairLayout(d->nodes, scenePairs, err)) return r;
+    hd.offSceneNodes = reserve(scenePairs.size() * sizeof(RtLinearNode));
     hd.offMeshes = reserve((size_t)std::max(d->meshCnt, 1) * sizeof(DevMesh));
 
     std::vector<DevMesh> meshes(std::max(d->meshCnt, 0));
+    std::vector<std::vector<RtLinearNode>> meshPairs(std::max(d->meshCnt, 0));
     for (int mi = 0; mi < d->meshCnt; ++mi) {
         const RtMesh& m = d->meshes[mi];
         DevMesh& dm = meshes[mi];
@@ -163,8 +229,10 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
         dm.triangleCnt = m.triangleCnt;
         dm.nodeCnt = m.nodeCnt;
         dm.vertexCnt = m.vertexCnt;
-        dm.offNodes = reserve((size_t)m.nodeCnt * sizeof(RtLinearNode));
-        dm.offTriRecords = reserve((size_t)m.triangleCnt * sizeof(TriRecord));
+        if (int r = pairLayout(m.nodes, meshPairs[mi], err)) return r;
+        dm.offNodes = reserve(meshPairs[mi].size() * sizeof(RtLinearNode));
+        // one spare record: the kernel fetches triangle records two at a time
+        dm.offTriRecords = reserve(((size_t)m.triangleCnt + 1) * sizeof(TriRecord));
         dm.offVertices = reserve((size_t)m.vertexCnt * sizeof(RtVertex));
         const RtTexture* tex[3] = {&m.diffuse, &m.normals, &m.specular};
         for (int k = 0; k < 3; ++k) {
@@ -176,8 +244,8 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
             dm.offTex[k] = reserve((size_t)tex[k]->width * tex[k]->height * 4);
         }
     }
-    if (hd.sceneDepth + hd.maxMeshDepth > RT_STACK_ENTRIES) {
-        *err = "BVH too deep for the kernel's traversal stack (scene depth + mesh depth > RT_STACK_ENTRIES)";
+    if (hd.sceneDepth + hd.maxMeshDepth + 1 > RT_STACK_ENTRIES) {
+        *err = "BVH too deep for the kernel's traversal stack (scene depth + mesh depth + 1 > RT_STACK_ENTRIES)";
         return RT_ERR_LIMIT;
     }
     hd.totalBytes = alignUp(cursor);
@@ -185,7 +253,7 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
     unsigned char* base = out.data();
 
     if (d->lightCnt) std::memcpy(base + hd.offLights, d->lights, (size_t)d->lightCnt * sizeof(RtLight));
-    std::memcpy(base + hd.offSceneNodes, d->nodes, (size_t)d->nodeCnt * sizeof(RtLinearNode));
+    std::memcpy(base + hd.offSceneNodes, scenePairs.data(), scenePairs.size() * sizeof(RtLinearNode));
     DevShape* shapes = reinterpret_cast<DevShape*>(base + hd.offShapes);
     for (int si = 0; si < d->shapeCnt; ++si) {
         const RtShape& s = d->shapes[si];
@@ -207,7 +275,7 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
     for (int mi = 0; mi < d->meshCnt; ++mi) {
         const RtMesh& m = d->meshes[mi];
         const DevMesh& dm = meshes[mi];
-        std::memcpy(base + dm.offNodes, m.nodes, (size_t)m.nodeCnt * sizeof(RtLinearNode));
+        std::memcpy(base + dm.offNodes, meshPairs[mi].data(), meshPairs[mi].size() * sizeof(RtLinearNode));
         std::memcpy(base + dm.offVertices, m.vertices, (size_t)m.vertexCnt * sizeof(RtVertex));
         TriRecord* rec = reinterpret_cast<TriRecord*>(base + dm.offTriRecords);
         for (int t = 0; t < m.triangleCnt; ++t) {
@@ -230,10 +298,43 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
     return RT_OK;
 }
 
+void freeWorkspace(Workspace& w) {
+    void* all[] = {w.ctl, w.hit, w.hitTri, w.color, w.secRay, w.child, w.kr, w.kind, w.ctx, w.ctxNode, w.vis};
+    for (void* p : all)
+        if (p) hipFree(p);
+    w = Workspace();
+}
+
+// Makes the workspace hold `nodeCap` path nodes (`slots` of them level 0) and `lights` lights.
+int ensureWorkspace(rt_ctx* ctx, int nodeCap, int slots, int lights) {
+    Workspace& w = ctx->ws;
+    const int secCap = nodeCap - slots;
+    if (w.ctl && nodeCap <= w.nodeCap && lights <= w.lightCap && secCap <= w.secCap) return RT_OK;
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // frames in flight still use the old arrays
+    const int nc = std::max(nodeCap, w.nodeCap), lc = std::max(std::max(lights, 1), w.lightCap), sc = std::max(secCap, w.secCap);
+    freeWorkspace(w);
+    const size_t n = (size_t)nc;
+    RT_HIP(ctx, hipMalloc(&w.ctl, CTL_WORDS * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc(&w.hit, n * 16));
+    RT_HIP(ctx, hipMalloc(&w.hitTri, n * 4));
+    RT_HIP(ctx, hipMalloc(&w.color, n * 16));
+    RT_HIP(ctx, hipMalloc(&w.secRay, std::max<size_t>((size_t)sc * 32, 256)));
+    RT_HIP(ctx, hipMalloc(&w.child, n * 4));
+    RT_HIP(ctx, hipMalloc(&w.kr, n * 4));
+    RT_HIP(ctx, hipMalloc(&w.kind, n * 4));
+    RT_HIP(ctx, hipMalloc(&w.ctx, n * 64));
+    RT_HIP(ctx, hipMalloc(&w.ctxNode, n * 4));
+    RT_HIP(ctx, hipMalloc(&w.vis, n * (size_t)lc));
+    w.nodeCap = nc;
+    w.lightCap = lc;
+    w.secCap = sc;
+    return RT_OK;
+}
+
 int checkHeader(rt_ctx* ctx, const BlobHeader& hd, size_t bytes) {
     if (hd.magic != RT_BLOB_MAGIC || hd.version != RT_BLOB_VERSION) return fail(ctx, RT_ERR_INVALID, "not a scene blob");
     if (hd.totalBytes != bytes) return fail(ctx, RT_ERR_INVALID, "scene blob size mismatch");
-    if (hd.sceneDepth + hd.maxMeshDepth > RT_STACK_ENTRIES) return fail(ctx, RT_ERR_LIMIT, "scene blob exceeds the traversal stack");
+    if (hd.sceneDepth + hd.maxMeshDepth + 1 > RT_STACK_ENTRIES) return fail(ctx, RT_ERR_LIMIT, "scene blob exceeds the traversal stack");
     return RT_OK;
 }
 
@@ -256,23 +357,19 @@ rt_ctx* rt_create(int device) {
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&ctx->tileQueue, 256) != hipSuccess) {
+        hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking) != hipSuccess) {
         fail(nullptr, RT_ERR_DEVICE, "cannot initialise device %d", device);
         delete ctx;
         return nullptr;
     }
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
         fail(nullptr, RT_ERR_DEVICE, "device %d is %s; this library only carries gfx950 code", device, prop.gcnArchName);
-        hipFree(ctx->tileQueue);
         hipStreamDestroy(ctx->ownStream);
         delete ctx;
         return nullptr;
     }
     ctx->cuCount = prop.multiProcessorCount;
     ctx->stream = ctx->ownStream;
-    for (int s = 0; s < 2; ++s)
-        for (int c = 0; c < 2; ++c) ctx->gridBlocks[s][c] = rtk_persistent_blocks(s, c, ctx->cuCount);
     return ctx;
 }
 
@@ -280,11 +377,9 @@ void rt_destroy(rt_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    for (auto& l : ctx->launches) {
-        hipEventDestroy(l.start);
-        hipEventDestroy(l.stop);
-    }
-    hipFree(ctx->tileQueue);
+    for (auto& l : ctx->launches)
+        for (hipEvent_t e : l.ev) hipEventDestroy(e);
+    freeWorkspace(ctx->ws);
     hipStreamDestroy(ctx->ownStream);
     delete ctx;
 }
@@ -301,6 +396,21 @@ int rt_sync(rt_ctx* ctx) {
     if (!ctx) return RT_ERR_INVALID;
     if (int r = bind(ctx)) return r;
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->ws.ctl) {
+        uint32_t overflow = 0;
+        RT_HIP(ctx, hipMemcpy(&overflow, static_cast<uint32_t*>(ctx->ws.ctl) + CTL_OVERFLOW, sizeof overflow, hipMemcpyDeviceToHost));
+        if (overflow)
+            return fail(ctx, RT_ERR_LIMIT,
+                        "reflection / refraction rays exceeded the path budget of %d x pixels; raise it with rt_set_path_budget",
+                        ctx->pathBudget);
+    }
+    return RT_OK;
+}
+
+int rt_set_path_budget(rt_ctx* ctx, int nodesPerPixel) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (nodesPerPixel < 1 || nodesPerPixel > 65536) return fail(ctx, RT_ERR_INVALID, "path budget must be in 1..65536");
+    ctx->pathBudget = nodesPerPixel;
     return RT_OK;
 }
 
@@ -475,7 +585,7 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     const BlobHeader& hd = scene->header;
     if (!opts->useSceneBvh && hd.maxMeshDepth > RT_STACK_ENTRIES) return fail(ctx, RT_ERR_LIMIT, "mesh BVH too deep");
 
-    RenderParams p;
+    FrameParams p;
     std::memset(&p, 0, sizeof p);
     p.blob = scene->blob;
     p.offLights = hd.offLights;
@@ -491,7 +601,6 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     p.pitch = pitch;
     p.hitKeys = aux ? aux->hitKeys : nullptr;
     p.counters = aux ? reinterpret_cast<unsigned long long*>(aux->counters) : nullptr;
-    p.tileQueue = ctx->tileQueue;
     p.tilesX = (opts->width + RT_TILE - 1) / RT_TILE;
     p.tilesY = (opts->height + RT_TILE - 1) / RT_TILE;
     const long long tiles = (long long)p.tilesX * p.tilesY;
@@ -500,25 +609,38 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     if (p.tileFirst < 0 || p.tileFirst >= p.tileStride) return fail(ctx, RT_ERR_INVALID, "tileFirst must be in [0, tileStride)");
     p.tileCnt = (int)((tiles - p.tileFirst + p.tileStride - 1) / p.tileStride);
     if (p.tileCnt <= 0) return RT_OK;
+    const long long slots = (long long)p.tileCnt * RT_TILE * RT_TILE;
+    const int secondary = hd.hasSecondary ? 1 : 0;
+    const long long nodeCap = slots * (secondary && opts->maxDepth > 0 ? ctx->pathBudget : 1);
+    if (nodeCap > 0x7fffffffLL / 4) return fail(ctx, RT_ERR_LIMIT, "frame too large for 32-bit node indices");
+    p.slots = (int)slots;
+    p.nodeCap = (int)nodeCap;
+    p.stackEntries = hd.sceneDepth + hd.maxMeshDepth + 1;
 
     if (int r = bind(ctx)) return r;
-    const int secondary = hd.hasSecondary ? 1 : 0;
-    const int count = p.counters ? 1 : 0;
-    const int grid = (int)std::min<long long>(ctx->gridBlocks[secondary][count], p.tileCnt);
+    if (int r = ensureWorkspace(ctx, p.nodeCap, p.slots, hd.lightCnt)) return r;
+    const Workspace& w = ctx->ws;
+    p.ctl = static_cast<uint32_t*>(w.ctl);
+    p.hit = static_cast<float4*>(w.hit);
+    p.hitTri = static_cast<int32_t*>(w.hitTri);
+    p.color = static_cast<float4*>(w.color);
+    p.secRay = static_cast<float4*>(w.secRay);
+    p.child = static_cast<int32_t*>(w.child);
+    p.kr = static_cast<float*>(w.kr);
+    p.kind = static_cast<int32_t*>(w.kind);
+    p.ctx = static_cast<float4*>(w.ctx);
+    p.ctxNode = static_cast<int32_t*>(w.ctxNode);
+    p.vis = static_cast<unsigned char*>(w.vis);
 
     if (ctx->launchesUsed == ctx->launches.size()) {
         if (ctx->launches.size() >= 65536) return fail(ctx, RT_ERR_LIMIT, "call rt_timing_reset: too many timed launches");
         TimedLaunch l;
-        RT_HIP(ctx, hipEventCreate(&l.start));
-        RT_HIP(ctx, hipEventCreate(&l.stop));
+        for (hipEvent_t& e : l.ev) RT_HIP(ctx, hipEventCreate(&e));
         ctx->launches.push_back(l);
     }
     TimedLaunch& l = ctx->launches[ctx->launchesUsed];
-    RT_HIP(ctx, hipMemsetAsync(ctx->tileQueue, 0, 256, ctx->stream));
-    RT_HIP(ctx, hipEventRecord(l.start, ctx->stream));
-    hipError_t e = (hipError_t)rtk_launch_render(&p, secondary, count, grid, ctx->stream);
+    hipError_t e = (hipError_t)rtk_render_frame(&p, secondary, p.counters ? 1 : 0, ctx->cuCount, ctx->stream, reinterpret_cast<void**>(l.ev));
     if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
-    RT_HIP(ctx, hipEventRecord(l.stop, ctx->stream));
     ctx->launchesUsed++;
     return RT_OK;
 }
@@ -529,17 +651,26 @@ int rt_timing_reset(rt_ctx* ctx) {
     return RT_OK;
 }
 
-int rt_timing_read(rt_ctx* ctx, double* totalMs, int* launches) {
+int rt_timing_read(rt_ctx* ctx, double* totalMs, int* launches) { return rt_timing_read_stages(ctx, totalMs, nullptr, launches); }
+
+int rt_timing_read_stages(rt_ctx* ctx, double* totalMs, double* stageMs, int* launches) {
     if (!ctx) return RT_ERR_INVALID;
     if (int r = bind(ctx)) return r;
-    double total = 0;
+    double total = 0, stage[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < ctx->launchesUsed; ++i) {
-        RT_HIP(ctx, hipEventSynchronize(ctx->launches[i].stop));
+        TimedLaunch& l = ctx->launches[i];
+        RT_HIP(ctx, hipEventSynchronize(l.ev[4]));
         float ms = 0;
-        RT_HIP(ctx, hipEventElapsedTime(&ms, ctx->launches[i].start, ctx->launches[i].stop));
+        RT_HIP(ctx, hipEventElapsedTime(&ms, l.ev[0], l.ev[4]));
         total += ms;
+        for (int k = 0; k < 4; ++k) {
+            RT_HIP(ctx, hipEventElapsedTime(&ms, l.ev[k], l.ev[k + 1]));
+            stage[k] += ms;
+        }
     }
     if (totalMs) *totalMs = total;
+    if (stageMs)
+        for (int k = 0; k < 4; ++k) stageMs[k] = stage[k];
     if (launches) *launches = (int)ctx->launchesUsed;
     return RT_OK;
 }

@@ -1,13 +1,34 @@
-// Device-side scene format shared by the packer (rt_capi.cpp) and the kernels
-// (kernels/rt_kernels.hip).  A scene lives in ONE contiguous, relocatable blob:
-// every reference inside it is a byte offset from the blob start, so the blob can
-// be copied between GPUs (RCCL broadcast) and used as is.
+// Device-side formats shared by the packer / frame driver (rt_capi.cpp) and
+// the kernels (kernels/rt_kernels.hip).
+//
+// SCENE BLOB.  A scene lives in ONE contiguous, relocatable blob: every
+// reference inside it is a byte offset from the blob start, so the blob can be
+// copied between GPUs (RCCL broadcast) and used as is.
 //
 //   [BlobHeader 256 B][lights][DevShape x shapeCnt][scene nodes 32 B each]
 //   [DevMesh x meshCnt] then per mesh: [mesh nodes 32 B][triangle records 48 B]
 //   [vertices 56 B][diffuse RGBA8][normals RGBA8][specular RGBA8]
 //
 // Every section starts on a 256-byte boundary.
+//
+// NODES.  The host hands over the reference's depth-first LinearNode arrays
+// (first child at self + 1).  The packer re-lays each tree out as SIBLING PAIRS:
+// record 0 is the root (record 1 is padding), and the two children of every
+// interior node sit next to each other at an even index, so that one 64-byte
+// fetch brings both child boxes.  A record is still 32 bytes:
+//   {bbmin[3], bbmax[3], ref, 0}
+// with `ref` describing the node itself (see the RT_REF_* macros): a leaf names
+// its primitive range, an interior node names its child pair and split axis.
+// Box values, split axes and leaf contents are untouched, so every box test
+// and the near/far visiting order are those of the original tree.
+//
+// FRAME WORKSPACE.  A frame is rendered as a sequence of ray "waves" over path
+// nodes.  A path node is one invocation of the reference's recursive castRay
+// (cudaTracer/tracer.cu:15-48): level-0 nodes are the pixels of the tiles this
+// call renders (64 per 8x8 tile), deeper nodes are reflection / refraction
+// children, appended per level.  Per level the driver runs
+//   trace (closest hit) -> shade -> trace (any hit, shadow rays) -> accumulate
+// and finally resolves mirror / glass nodes bottom-up and writes the pixels.
 #ifndef RT_DEVICE_FORMAT_H
 #define RT_DEVICE_FORMAT_H
 
@@ -16,8 +37,20 @@
 #include "../../include/rt_capi.h"
 
 #define RT_BLOB_MAGIC 0x52544246u /* "RTBF" */
-#define RT_BLOB_VERSION 1u
-#define RT_TILE 8 /* 8x8 pixels = one 64-lane wavefront */
+#define RT_BLOB_VERSION 2u
+#define RT_TILE 8 /* 8x8 pixels = 64 level-0 path nodes */
+
+/* 32-bit node reference.
+ *   leaf:     bit 31 set | primitive count (7 bits) << 24 | first primitive (24 bits)
+ *   interior: split axis (2 bits) << 29 | index of the child pair / 2 (29 bits) */
+#define RT_REF_LEAF 0x80000000u
+#define RT_REF_MAX_LEAF_PRIMS 127
+#define RT_REF_MAX_PRIMS (1 << 24)
+#define RT_REF_IS_LEAF(r) (((r)&RT_REF_LEAF) != 0u)
+#define RT_REF_LEAF_COUNT(r) (((r) >> 24) & 0x7fu)
+#define RT_REF_LEAF_FIRST(r) ((r)&0xffffffu)
+#define RT_REF_AXIS(r) (((r) >> 29) & 3u)
+#define RT_REF_PAIR(r) (((r)&0x1fffffffu) << 1)
 
 struct BlobHeader {
     uint32_t magic;
@@ -86,28 +119,59 @@ static_assert(sizeof(DevMesh) == 192, "DevMesh size");
 static_assert(sizeof(TriRecord) == 48, "TriRecord size");
 #endif
 
-// Arguments of one render launch (passed by value as the kernel argument).
-struct RenderParams {
+// ---- frame workspace ------------------------------------------------------
+// Control block (uint32 words in device memory, zeroed at frame start).
+enum {
+    CTL_TRACE_QUEUE = 0,   // head of the closest-hit work queue of the current level
+    CTL_SHADOW_QUEUE = 1,  // head of the shadow-ray work queue of the current level
+    CTL_DIFFUSE_CNT = 2,   // diffuse hits of the current level
+    CTL_OVERFLOW = 3,      // set when a child ray did not fit the node arrays
+    CTL_LEVEL_START = 8,   // [RT_MAX_DEPTH + 2] first node of each level
+    CTL_LEVEL_COUNT = 40,  // [RT_MAX_DEPTH + 2] nodes of each level
+    CTL_WORDS = 128
+};
+
+// Node kinds written by the shade kernel.
+enum { NODE_DONE = 0, NODE_MIRROR = 1, NODE_GLASS = 2 };
+
+struct FrameParams {
+    // scene
     const unsigned char* blob;
     uint64_t offLights, offShapes, offSceneNodes, offMeshes;
     int32_t lightCnt, shapeCnt;
+    // per-frame inputs
     RtDeviceOpts opts;
     float orig[3];
     float camera[16];
+    // outputs
     unsigned char* surface;
     uint64_t pitch;
     int32_t* hitKeys;
     unsigned long long* counters;
-    unsigned int* tileQueue;  // zeroed before the launch
+    // tile shard
     int32_t tilesX, tilesY;
-    int32_t tileFirst, tileStride, tileCnt;  // this launch renders tiles tileFirst + k*tileStride, k < tileCnt
+    int32_t tileFirst, tileStride, tileCnt;  // this call renders tiles tileFirst + k*tileStride, k < tileCnt
+    int32_t slots;                           // tileCnt * 64 level-0 nodes
+    int32_t nodeCap;                         // capacity of the per-node arrays
+    int32_t stackEntries;                    // per-lane traversal stack entries in LDS (8 bytes each)
+    // workspace (device pointers)
+    uint32_t* ctl;          // CTL_WORDS
+    float4* hit;            // [nodeCap] {t, u, v, shape slot as int bits (-1 miss, -2 outside the frame)}
+    int32_t* hitTri;        // [nodeCap] triangle record of the hit
+    float4* color;          // [nodeCap] radiance returned by the node
+    float4* secRay;         // [2 * (nodeCap - slots)] origin, direction of nodes beyond level 0
+    int32_t* child;         // [nodeCap] first child node (mirror: 1 child, glass: 2 consecutive)
+    float* kr;              // [nodeCap] Fresnel term of mirror / glass nodes
+    int32_t* kind;          // [nodeCap] NODE_*
+    float4* ctx;            // [4 * nodeCap] shading context of each diffuse hit of the current level
+    int32_t* ctxNode;       // [nodeCap] node of each diffuse hit
+    unsigned char* vis;     // [nodeCap * max(lightCnt,1)] 1 = light visible
 };
 
-// Launcher implemented in kernels/rt_kernels.hip.  `secondary` selects the
-// variant with the bounce stack, `count` the one that tallies test counters.
+// Enqueues all kernels of one frame on `stream` (no host synchronisation).
+// `stageEvents`: optional hipEvent_t[5] recorded at frame start, after the
+// level-0 closest-hit trace, after shading, after the shadow trace, at frame end.
 // Returns a hipError_t value.
-int rtk_launch_render(const RenderParams* p, int secondary, int count, int gridBlocks, void* stream);
-// Waves that fit the device for the chosen variant (persistent grid size).
-int rtk_persistent_blocks(int secondary, int count, int cuCount);
+int rtk_render_frame(const FrameParams* p, int hasSecondary, int count, int cuCount, void* stream, void** stageEvents);
 
 #endif

@@ -38,11 +38,11 @@ extern "C" {
 /* Deepest recursion level the kernel's bounce stack holds (levels 0..maxDepth
  * are traced, cudaTracer/tracer.cu:16). */
 #define RT_MAX_DEPTH 15
-/* Per-ray traversal stack entries (scene BVH + mesh BVH share one stack).
- * The reference reserves int[64] per level (cudaTracer/Scene.cuh:36,
- * cudaTracer/Mesh.cuh:135); a median-split tree over 10 M triangles is 21
- * levels deep, so 32 covers every balanced tree the host builder emits.  */
-#define RT_STACK_ENTRIES 32
+/* Largest per-ray traversal stack (scene BVH + mesh BVH share one stack; the
+ * launch sizes it to scene depth + deepest mesh depth + 1).  The reference
+ * reserves int[64] per level (cudaTracer/Scene.cuh:36, cudaTracer/Mesh.cuh:135);
+ * a median-split tree over 10 M triangles is 21 levels deep.                 */
+#define RT_STACK_ENTRIES 64
 
 /* ---- plain-data mirrors of the reference's device structs --------------- */
 
@@ -258,10 +258,18 @@ void rt_device_free(rt_ctx* ctx, void* devPtr);
 int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCamera* cam,
               void* devSurface, size_t pitch, int blockDim, const RtFrameAux* aux);
 
-/* HIP-event timing of the render kernel launches since the last reset, on the
- * stream they ran on.  Call after rt_sync. */
+/* HIP-event timing of the rt_render calls since the last reset, measured on the
+ * stream they ran on.  Call after rt_sync.  totalMs sums the whole per-frame
+ * kernel sequence; stageMs[4] (may be NULL) splits it into: closest-hit trace of
+ * the primary rays, shading, shadow-ray trace, everything after. */
 int rt_timing_reset(rt_ctx* ctx);
 int rt_timing_read(rt_ctx* ctx, double* totalMs, int* launches);
+int rt_timing_read_stages(rt_ctx* ctx, double* totalMs, double* stageMs, int* launches);
+
+/* Mirror / glass materials spawn child rays (cudaTracer/tracer.cu:117-142); the
+ * per-frame node arrays hold `nodesPerPixel` x pixels path nodes (default 3).
+ * A frame that needs more reports RT_ERR_LIMIT from rt_sync. */
+int rt_set_path_budget(rt_ctx* ctx, int nodesPerPixel);
 
 /* cu_initCurand / cu_cleanCurand (cudaTracer/Main.cu:113-150) have no
  * counterpart: samples == 1 draws no random numbers. */

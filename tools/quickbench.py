@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Stage timing of the frame pipeline on one GPU (development aid).
+
+  python tools/quickbench.py [--scene soup] [--size 1000000] [--lights 1] [--steps 10]
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cudaraytracer_amd as rt  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--scene", default="soup")
+ap.add_argument("--size", type=int, default=1000000)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--lights", type=int, default=1)
+ap.add_argument("--max-depth", type=int, default=0)
+ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--reference-bvh", action="store_true")
+a = ap.parse_args()
+
+t = time.time()
+scene = rt.HostScene(a.scene, a.width, a.height, a.size, a.lights, a.max_depth, tight_bvh=not a.reference_bvh)
+print(f"scene {a.scene} size {a.size}: built in {time.time()-t:.2f}s, depth {scene.bvh_depth()}", flush=True)
+with rt.Context(0) as ctx:
+    ds = ctx.upload(scene)
+    surf, pitch = ctx.surface(a.width, a.height)
+    cnt = ctx.alloc(rt.RT_COUNTER_CNT * 8)
+    ctx.render(ds, scene.opts, scene.camera, surf, pitch, None, cnt)
+    ctx.sync()
+    import numpy as np
+    c = ctx.download(cnt, (rt.RT_COUNTER_CNT,), np.uint64)
+    c = {n: int(c[i]) for i, n in enumerate(rt.RT_COUNTER_NAMES)}
+    rays = c["primary"] + c["shadow"] + c["secondary"]
+    for _ in range(2):
+        ctx.render(ds, scene.opts, scene.camera, surf, pitch)
+    ctx.sync()
+    ctx.timing_reset()
+    for _ in range(a.steps):
+        ctx.render(ds, scene.opts, scene.camera, surf, pitch)
+    ctx.sync()
+    total, st, n = ctx.timing_read_stages()
+    print(f"rays/frame {rays} (primary {c['primary']} shadow {c['shadow']} secondary {c['secondary']}), node/ray {c['node']/rays:.1f} tri/ray {c['tri']/rays:.1f}")
+    print(f"frame {total/n:.3f} ms  | primary-trace {st[0]/n:.3f}  shade {st[1]/n:.3f}  shadow-trace {st[2]/n:.3f}  rest {st[3]/n:.3f}  | {rays/(total/n)/1e3:.1f} Mrays/s", flush=True)
