@@ -8,10 +8,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librt_gfx950.so")
+# RT_LIB (development only) selects another build of the same library, e.g. a tuning variant
+LIB_PATH = os.environ.get("RT_LIB") or os.path.join(_HERE, "librt_gfx950.so")
 
 RT_COUNTER_NAMES = ["primary", "shadow", "secondary", "node", "tri", "sphere", "mesh_entry", "shade_mesh", "shade_sphere"]
-RT_COUNTER_CNT = 16
+RT_COUNTER_CNT = 32
 RT_MAX_DEPTH = 15
 RT_STACK_ENTRIES = 32
 
@@ -106,6 +107,9 @@ C_ABI = {
     "rt_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "rt_timing_read_stages": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "rt_set_path_budget": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_set_lds_stack": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_set_subframes": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_set_trace_waves": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 HARNESS = {

@@ -215,6 +215,15 @@ class Context:
     def set_path_budget(self, nodes_per_pixel):
         self._check(self.lib.rt_set_path_budget(self.ctx, nodes_per_pixel), "rt_set_path_budget")
 
+    def set_trace_waves(self, waves_per_cu):
+        self._check(self.lib.rt_set_trace_waves(self.ctx, waves_per_cu), "rt_set_trace_waves")
+
+    def set_subframes(self, count):
+        self._check(self.lib.rt_set_subframes(self.ctx, count), "rt_set_subframes")
+
+    def set_lds_stack(self, entries):
+        self._check(self.lib.rt_set_lds_stack(self.ctx, entries), "rt_set_lds_stack")
+
     def render_frame(self, host_scene, scene=None, want_keys=False, want_counters=False):
         """Convenience: full frame of a HostScene -> (rgba[h,w,4], keys or None, counters dict or None)."""
         own = scene is None

@@ -45,10 +45,14 @@ def _run(cmd):
     subprocess.check_call(cmd)
 
 
-def build_library(force=False, extra_device_flags=()):
-    if not force and not _newer(LIB, _sources()):
-        return LIB
-    objdir = os.path.join(PKG, "build")
+def build_library(force=False, extra_device_flags=(), out=None, tag=""):
+    """Builds the library; `out` / `tag` / `extra_device_flags` produce a tuning variant beside the default build."""
+    global LIB
+    if out is None:
+        out = LIB
+    if not force and not _newer(out, _sources()):
+        return out
+    objdir = os.path.join(PKG, "build" + tag)
     os.makedirs(objdir, exist_ok=True)
     objs = []
     kern = os.path.join(CSRC, "kernels", "rt_kernels.hip")
@@ -60,8 +64,8 @@ def build_library(force=False, extra_device_flags=()):
         o = os.path.join(objdir, os.path.basename(rel).replace(".cpp", ".o"))
         _run([HIPCC, "-x", "c++", *HOST_FLAGS, "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c", src, "-o", o])
         objs.append(o)
-    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-lz"])
-    return LIB
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-lz"])
+    return out
 
 
 def build_oracle(force=False):

@@ -30,9 +30,21 @@
 namespace {
 
 constexpr int kWave = 64;
-constexpr unsigned kChunk = 256;  // rays a wavefront takes from the global queue per atomic
+#ifndef RT_CHUNK
+#define RT_CHUNK 64
+#endif
+constexpr unsigned kChunk = RT_CHUNK;  // rays a wavefront takes from the global queue per atomic
 #ifndef RT_REFILL_LANES
-#define RT_REFILL_LANES 16  // a wavefront refills once this many lanes have finished their rays
+#define RT_REFILL_LANES 8  // a wavefront refills once this many lanes have finished their rays
+#endif
+#ifndef RT_TRI_BATCH
+#define RT_TRI_BATCH 4  // triangle records fetched and tested per step (the packer pads the record array accordingly)
+#endif
+#ifndef RT_TRI_LANES
+#define RT_TRI_LANES 20  // triangle steps start once this many lanes wait in a leaf
+#endif
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 1  // __launch_bounds__ waves per SIMD for the trace kernel
 #endif
 
 struct V3 {
@@ -251,10 +263,13 @@ enum { MODE_NODE = 0, MODE_TRI = 1, MODE_SHAPE = 2, MODE_POP = 3, MODE_DONE = 4 
 // also pushes far children that are already known to fail (marked by an
 // infinite entry distance).
 template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(kWave) traceKernel(const FrameParams P, const int level) {
+__global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FrameParams P, const int level) {
     extern __shared__ uint2 s_stack[];
     const int lane = threadIdx.x;
     uint2* const stk = s_stack + lane;
+    // entries beyond the LDS part of the stack live in this wavefront's slice of a global array
+    const int ldsEntries = P.stackLds;
+    uint2* const gstk = P.stackSpill + ((size_t)blockIdx.x * (size_t)(P.stackEntries - P.stackLds)) * kWave + lane;
 
     const unsigned total = ANY ? P.ctl[CTL_DIFFUSE_CNT] * (unsigned)P.lightCnt : P.ctl[CTL_LEVEL_COUNT + level];
     const unsigned first = ANY ? 0u : P.ctl[CTL_LEVEL_START + level];
@@ -268,6 +283,8 @@ __global__ void __launch_bounds__(kWave) traceKernel(const FrameParams P, const 
     const float kInf = __builtin_huge_valf();
 
     unsigned cNode = 0, cTri = 0, cSphere = 0, cMesh = 0, cRays = 0, cPrimary = 0;
+    // wave-level step statistics (lane 0 only): steps, lanes expanding nodes, lanes testing triangles, lanes with a ray
+    unsigned long long wSteps = 0, wNodeLanes = 0, wTriLanes = 0, wBusyLanes = 0, wNodeSteps = 0, wTriSteps = 0;
 
     // wave-uniform queue state
     unsigned chunkNext = 0, chunkEnd = 0;
@@ -400,20 +417,44 @@ __global__ void __launch_bounds__(kWave) traceKernel(const FrameParams P, const 
 
         // ---- advance every active lane until enough lanes have finished -----
         while (true) {
-            // one fetch per step: the child pair of an interior node, or two triangle records
-            const bool isNode = mode == MODE_NODE, isTri = mode == MODE_TRI;
-            float4 L0, L1, L2, L3, L4;
-            float L5 = 0.0f;
-            L0 = L1 = L2 = L3 = L4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (isNode || isTri) {
-                const float4* p = isNode ? nodes + 2 * (size_t)RT_REF_PAIR(ref) : tris + 3 * (size_t)triNext;
+            // One kind of step per iteration for the whole wavefront: either every lane that sits
+            // on an interior node expands it, or every lane that sits in a leaf tests triangles.
+            // Lanes of the other kind wait, so each (long) block runs with many lanes instead of
+            // both blocks running half empty.  Triangle steps are taken once enough lanes have
+            // reached a leaf, or when nobody has a node to expand.
+            const unsigned long long nodeLanes = __ballot(mode == MODE_NODE);
+            const unsigned long long triLanes = __ballot(mode == MODE_TRI);
+            const bool triStep = triLanes != 0ull && (__popcll(triLanes) >= RT_TRI_LANES || nodeLanes == 0ull);
+            const bool isNode = !triStep && mode == MODE_NODE, isTri = triStep && mode == MODE_TRI;
+            if (COUNT) {
+                wSteps++;
+                wBusyLanes += __popcll(__ballot(item >= 0 && mode != MODE_DONE));
+                if (triStep) {
+                    wTriSteps++;
+                    wTriLanes += __popcll(triLanes);
+                } else if (nodeLanes != 0ull) {
+                    wNodeSteps++;
+                    wNodeLanes += __popcll(nodeLanes);
+                }
+            }
+            float4 L0, L1, L2, L3;
+            float4 TA[RT_TRI_BATCH], TB[RT_TRI_BATCH];
+            float TC[RT_TRI_BATCH];
+            L0 = L1 = L2 = L3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (isNode) {
+                const float4* p = nodes + 2 * (size_t)RT_REF_PAIR(ref);
                 L0 = p[0];
                 L1 = p[1];
                 L2 = p[2];
                 L3 = p[3];
-                if (isTri) {
-                    L4 = p[4];
-                    L5 = reinterpret_cast<const float*>(p + 5)[0];
+            }
+            if (isTri) {
+                const float4* p = tris + 3 * (size_t)triNext;
+#pragma unroll
+                for (int k = 0; k < RT_TRI_BATCH; ++k) {
+                    TA[k] = p[3 * k];
+                    TB[k] = p[3 * k + 1];
+                    TC[k] = reinterpret_cast<const float*>(p + 3 * k + 2)[0];
                 }
             }
             if (isNode) {
@@ -430,7 +471,11 @@ __global__ void __launch_bounds__(kWave) traceKernel(const FrameParams P, const 
                 const float nearT = negAxis ? t1 : t0, farT = negAxis ? t0 : t1;
                 const bool farHit = farGeo && farT < tMax;
                 if (COUNT || farHit) {
-                    stk[sp * kWave] = make_uint2(farRef, __float_as_uint(farHit ? farT : kInf));
+                    const uint2 e = make_uint2(farRef, __float_as_uint(farHit ? farT : kInf));
+                    if (sp < ldsEntries)
+                        stk[sp * kWave] = e;
+                    else
+                        gstk[(size_t)(sp - ldsEntries) * kWave] = e;
                     ++sp;
                 }
                 if (COUNT) cNode++;
@@ -441,21 +486,18 @@ __global__ void __launch_bounds__(kWave) traceKernel(const FrameParams P, const 
             }
             if (isTri) {
                 // cudaTracer/Mesh.cuh:141-146: leaf triangles in order; a later hit at equal t replaces an earlier one
-                if (COUNT) cTri++;
-                if (triangleHit(L0, L1, L2.x, o, d, tMax, hu, hv)) {
-                    hTri = triNext;
-                    blasHit = true;
-                    if (ANY) hitAny = true;
-                }
-                if (!(ANY && hitAny) && triNext + 1 < triEnd) {
-                    if (COUNT) cTri++;
-                    if (triangleHit(L3, L4, L5, o, d, tMax, hu, hv)) {
-                        hTri = triNext + 1;
-                        blasHit = true;
-                        if (ANY) hitAny = true;
+#pragma unroll
+                for (int k = 0; k < RT_TRI_BATCH; ++k) {
+                    if (!(ANY && hitAny) && triNext + k < triEnd) {
+                        if (COUNT) cTri++;
+                        if (triangleHit(TA[k], TB[k], TC[k], o, d, tMax, hu, hv)) {
+                            hTri = triNext + k;
+                            blasHit = true;
+                            if (ANY) hitAny = true;
+                        }
                     }
                 }
-                triNext += 2;
+                triNext += RT_TRI_BATCH;
                 if (ANY && hitAny)
                     mode = MODE_DONE;
                 else if (triNext >= triEnd)
@@ -508,7 +550,8 @@ __global__ void __launch_bounds__(kWave) traceKernel(const FrameParams P, const 
             }
             while (mode == MODE_POP) {
                 if (sp > base) {
-                    const uint2 e = stk[(--sp) * kWave];
+                    --sp;
+                    const uint2 e = sp < ldsEntries ? stk[sp * kWave] : gstk[(size_t)(sp - ldsEntries) * kWave];
                     if (COUNT) cNode++;
                     if (__uint_as_float(e.y) < tMax) RT_ENTER(e.x);
                 } else if (inBlas) {
@@ -560,6 +603,15 @@ __global__ void __launch_bounds__(kWave) traceKernel(const FrameParams P, const 
             unsigned v = vals[i];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
             if (lane == 0 && v && where[i] >= 0) atomicAdd(P.counters + where[i], (unsigned long long)v);
+        }
+        if (lane == 0) {
+            const int b = ANY ? RT_CNT_STAT_SHADOW : RT_CNT_STAT_CLOSEST;
+            atomicAdd(P.counters + b + 0, wSteps);
+            atomicAdd(P.counters + b + 1, wNodeSteps);
+            atomicAdd(P.counters + b + 2, wNodeLanes);
+            atomicAdd(P.counters + b + 3, wTriSteps);
+            atomicAdd(P.counters + b + 4, wTriLanes);
+            atomicAdd(P.counters + b + 5, wBusyLanes);
         }
     }
 }
@@ -917,47 +969,88 @@ __global__ void advanceKernel(const FrameParams P, const int level) {
 
 template <bool ANY, bool COUNT>
 void launchTrace(const FrameParams& p, int level, int cuCount, hipStream_t s) {
-    const size_t lds = (size_t)p.stackEntries * kWave * sizeof(uint2);
+    const size_t lds = (size_t)p.stackLds * kWave * sizeof(uint2);
+    hipLaunchKernelGGL((traceKernel<ANY, COUNT>), dim3(p.traceWaves), dim3(kWave), lds, s, p, level);
+}
+
+template <bool ANY, bool COUNT>
+int wavesPerCu(size_t lds) {
     int perCu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, traceKernel<ANY, COUNT>, kWave, lds) != hipSuccess || perCu < 1) perCu = 8;
-    if (perCu > 32) perCu = 32;
-    hipLaunchKernelGGL((traceKernel<ANY, COUNT>), dim3(perCu * cuCount), dim3(kWave), lds, s, p, level);
+    return perCu > 32 ? 32 : perCu;
 }
 
 }  // namespace
 
-int rtk_render_frame(const FrameParams* pp, int hasSecondary, int count, int cuCount, void* stream, void** stageEvents) {
-    const FrameParams& p = *pp;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+int rtk_trace_waves_per_cu(int stackLds) {
+    const size_t lds = (size_t)stackLds * kWave * sizeof(uint2);
+    // one grid size for all four variants: the smallest residency, so that every wave of the grid is resident
+    int w = wavesPerCu<false, false>(lds);
+    w = w < wavesPerCu<true, false>(lds) ? w : wavesPerCu<true, false>(lds);
+    w = w < wavesPerCu<false, true>(lds) ? w : wavesPerCu<false, true>(lds);
+    w = w < wavesPerCu<true, true>(lds) ? w : wavesPerCu<true, true>(lds);
+    return w;
+}
+
+// Enqueues the kernel sequence of `nSubs` sub-frames.  With one sub-frame everything runs on
+// `stream`.  With several, sub-frame i runs on subStreams[i] between a fork event recorded on
+// `stream` and a join back into it, so that the draining tail of one sub-frame's persistent
+// trace kernel overlaps with the next sub-frame's work instead of leaving wave slots empty.
+int rtk_render_frame(const FrameParams* subs, int nSubs, int hasSecondary, int count, int cuCount, void* stream, void** subStreams,
+                     void** subEvents, void** stageEvents) {
+    hipStream_t mainStream = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t* ev = reinterpret_cast<hipEvent_t*>(stageEvents);
-    const int lastLevel = hasSecondary ? p.opts.maxDepth : 0;
+    hipEvent_t* fj = reinterpret_cast<hipEvent_t*>(subEvents);
+    const bool split = nSubs > 1;
+    const int lastLevel = hasSecondary ? subs[0].opts.maxDepth : 0;
     const dim3 wide(cuCount * 8), block(256);
-    hipError_t e = hipMemsetAsync(p.ctl, 0, CTL_WORDS * sizeof(uint32_t), s);
-    if (e != hipSuccess) return (int)e;
-    if (ev) (void)hipEventRecord(ev[0], s);
-    for (int level = 0; level <= lastLevel; ++level) {
-        hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(64), 0, s, p, level);
-        if (count)
-            launchTrace<false, true>(p, level, cuCount, s);
-        else
-            launchTrace<false, false>(p, level, cuCount, s);
-        if (ev && level == 0) (void)hipEventRecord(ev[1], s);
-        if (count)
-            hipLaunchKernelGGL((shadeKernel<true>), wide, block, 0, s, p, level);
-        else
-            hipLaunchKernelGGL((shadeKernel<false>), wide, block, 0, s, p, level);
-        if (ev && level == 0) (void)hipEventRecord(ev[2], s);
-        if (p.lightCnt > 0) {
-            if (count)
-                launchTrace<true, true>(p, level, cuCount, s);
-            else
-                launchTrace<true, false>(p, level, cuCount, s);
-        }
-        if (ev && level == 0) (void)hipEventRecord(ev[3], s);
-        hipLaunchKernelGGL(accumKernel, wide, block, 0, s, p);
+    auto streamOf = [&](int i) { return split ? reinterpret_cast<hipStream_t>(subStreams[i]) : mainStream; };
+    if (ev) (void)hipEventRecord(ev[0], mainStream);
+    if (split) {
+        (void)hipEventRecord(fj[0], mainStream);
+        for (int i = 0; i < nSubs; ++i) (void)hipStreamWaitEvent(streamOf(i), fj[0], 0);
+        if (ev)
+            for (int k = 1; k < 4; ++k) (void)hipEventRecord(ev[k], mainStream);  // no per-stage split in this mode
     }
-    for (int level = lastLevel - 1; level >= 0; --level) hipLaunchKernelGGL(resolveKernel, wide, block, 0, s, p, level);
-    hipLaunchKernelGGL(finalizeKernel, wide, block, 0, s, p);
-    if (ev) (void)hipEventRecord(ev[4], s);
+    for (int i = 0; i < nSubs; ++i) {
+        hipError_t e = hipMemsetAsync(subs[i].ctl, 0, CTL_WORDS * sizeof(uint32_t), streamOf(i));
+        if (e != hipSuccess) return (int)e;
+    }
+    for (int level = 0; level <= lastLevel; ++level) {
+        for (int i = 0; i < nSubs; ++i) {
+            const FrameParams& p = subs[i];
+            hipStream_t s = streamOf(i);
+            hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(64), 0, s, p, level);
+            if (count)
+                launchTrace<false, true>(p, level, cuCount, s);
+            else
+                launchTrace<false, false>(p, level, cuCount, s);
+            if (ev && !split && level == 0) (void)hipEventRecord(ev[1], s);
+            if (count)
+                hipLaunchKernelGGL((shadeKernel<true>), wide, block, 0, s, p, level);
+            else
+                hipLaunchKernelGGL((shadeKernel<false>), wide, block, 0, s, p, level);
+            if (ev && !split && level == 0) (void)hipEventRecord(ev[2], s);
+            if (p.lightCnt > 0) {
+                if (count)
+                    launchTrace<true, true>(p, level, cuCount, s);
+                else
+                    launchTrace<true, false>(p, level, cuCount, s);
+            }
+            if (ev && !split && level == 0) (void)hipEventRecord(ev[3], s);
+            hipLaunchKernelGGL(accumKernel, wide, block, 0, s, p);
+        }
+    }
+    for (int i = 0; i < nSubs; ++i) {
+        const FrameParams& p = subs[i];
+        hipStream_t s = streamOf(i);
+        for (int level = lastLevel - 1; level >= 0; --level) hipLaunchKernelGGL(resolveKernel, wide, block, 0, s, p, level);
+        hipLaunchKernelGGL(finalizeKernel, wide, block, 0, s, p);
+        if (split) {
+            (void)hipEventRecord(fj[1 + i], s);
+            (void)hipStreamWaitEvent(mainStream, fj[1 + i], 0);
+        }
+    }
+    if (ev) (void)hipEventRecord(ev[4], mainStream);
     return (int)hipGetLastError();
 }

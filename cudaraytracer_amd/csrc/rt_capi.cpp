@@ -16,6 +16,13 @@
 #include "../../include/rt_capi.h"
 #include "rt_device_format.h"
 
+#ifndef RT_SUBFRAMES_DEFAULT
+#define RT_SUBFRAMES_DEFAULT 1
+#endif
+#ifndef RT_LDS_STACK_DEFAULT
+#define RT_LDS_STACK_DEFAULT 20
+#endif
+
 namespace {
 
 thread_local std::string g_createError;
@@ -42,6 +49,8 @@ struct Workspace {
     void* ctx = nullptr;
     void* ctxNode = nullptr;
     void* vis = nullptr;
+    void* stackSpill = nullptr;
+    size_t spillBytes = 0;
 };
 
 }  // namespace
@@ -53,6 +62,12 @@ struct rt_ctx {
     hipStream_t stream = nullptr;
     Workspace ws;
     int pathBudget = 3;  // node arrays hold pathBudget x pixels when the scene has mirror / glass materials
+    int ldsStack = RT_LDS_STACK_DEFAULT;  // traversal stack entries kept in LDS (deeper ones spill to global memory)
+    int subFrames = RT_SUBFRAMES_DEFAULT;  // concurrent sub-frames per rt_render call
+    int maxWavesPerCu = 0;                 // 0 = as many as are resident
+    hipStream_t subStreams[RT_MAX_SUBFRAMES] = {};
+    hipEvent_t subEvents[RT_MAX_SUBFRAMES + 1] = {};
+    int wavesPerCu = 0, wavesForLds = -1;
     std::string error;
     std::vector<TimedLaunch> launches;  // events of launches since the last reset
     size_t launchesUsed = 0;
@@ -231,8 +246,8 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
         dm.vertexCnt = m.vertexCnt;
         if (int r = pairLayout(m.nodes, meshPairs[mi], err)) return r;
         dm.offNodes = reserve(meshPairs[mi].size() * sizeof(RtLinearNode));
-        // one spare record: the kernel fetches triangle records two at a time
-        dm.offTriRecords = reserve(((size_t)m.triangleCnt + 1) * sizeof(TriRecord));
+        // spare records: the kernel fetches up to four triangle records per step
+        dm.offTriRecords = reserve(((size_t)m.triangleCnt + 4) * sizeof(TriRecord));
         dm.offVertices = reserve((size_t)m.vertexCnt * sizeof(RtVertex));
         const RtTexture* tex[3] = {&m.diffuse, &m.normals, &m.specular};
         for (int k = 0; k < 3; ++k) {
@@ -299,22 +314,38 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
 }
 
 void freeWorkspace(Workspace& w) {
-    void* all[] = {w.ctl, w.hit, w.hitTri, w.color, w.secRay, w.child, w.kr, w.kind, w.ctx, w.ctxNode, w.vis};
+    void* all[] = {w.ctl, w.hit, w.hitTri, w.color, w.secRay, w.child, w.kr, w.kind, w.ctx, w.ctxNode, w.vis, w.stackSpill};
     for (void* p : all)
         if (p) hipFree(p);
     w = Workspace();
 }
 
 // Makes the workspace hold `nodeCap` path nodes (`slots` of them level 0) and `lights` lights.
-int ensureWorkspace(rt_ctx* ctx, int nodeCap, int slots, int lights) {
+int ensureWorkspace(rt_ctx* ctx, int nodeCap, int slots, int lights, size_t spillBytes) {
     Workspace& w = ctx->ws;
     const int secCap = nodeCap - slots;
+    if (spillBytes > w.spillBytes) {
+        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (w.stackSpill) hipFree(w.stackSpill);
+        w.stackSpill = nullptr;
+        w.spillBytes = 0;
+        RT_HIP(ctx, hipMalloc(&w.stackSpill, spillBytes));
+        w.spillBytes = spillBytes;
+    }
     if (w.ctl && nodeCap <= w.nodeCap && lights <= w.lightCap && secCap <= w.secCap) return RT_OK;
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // frames in flight still use the old arrays
     const int nc = std::max(nodeCap, w.nodeCap), lc = std::max(std::max(lights, 1), w.lightCap), sc = std::max(secCap, w.secCap);
-    freeWorkspace(w);
+    {
+        void* keepSpill = w.stackSpill;
+        const size_t keepBytes = w.spillBytes;
+        w.stackSpill = nullptr;
+        freeWorkspace(w);
+        w.stackSpill = keepSpill;
+        w.spillBytes = keepBytes;
+    }
     const size_t n = (size_t)nc;
-    RT_HIP(ctx, hipMalloc(&w.ctl, CTL_WORDS * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc(&w.ctl, RT_MAX_SUBFRAMES * CTL_WORDS * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMemset(w.ctl, 0, RT_MAX_SUBFRAMES * CTL_WORDS * sizeof(uint32_t)));
     RT_HIP(ctx, hipMalloc(&w.hit, n * 16));
     RT_HIP(ctx, hipMalloc(&w.hitTri, n * 4));
     RT_HIP(ctx, hipMalloc(&w.color, n * 16));
@@ -370,6 +401,14 @@ rt_ctx* rt_create(int device) {
     }
     ctx->cuCount = prop.multiProcessorCount;
     ctx->stream = ctx->ownStream;
+    bool ok = true;
+    for (int i = 0; i < RT_MAX_SUBFRAMES; ++i) ok = ok && hipStreamCreateWithFlags(&ctx->subStreams[i], hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i <= RT_MAX_SUBFRAMES; ++i) ok = ok && hipEventCreateWithFlags(&ctx->subEvents[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        fail(nullptr, RT_ERR_DEVICE, "cannot create streams / events on device %d", device);
+        rt_destroy(ctx);
+        return nullptr;
+    }
     return ctx;
 }
 
@@ -380,6 +419,10 @@ void rt_destroy(rt_ctx* ctx) {
     for (auto& l : ctx->launches)
         for (hipEvent_t e : l.ev) hipEventDestroy(e);
     freeWorkspace(ctx->ws);
+    for (hipStream_t st : ctx->subStreams)
+        if (st) hipStreamDestroy(st);
+    for (hipEvent_t e : ctx->subEvents)
+        if (e) hipEventDestroy(e);
     hipStreamDestroy(ctx->ownStream);
     delete ctx;
 }
@@ -397,13 +440,36 @@ int rt_sync(rt_ctx* ctx) {
     if (int r = bind(ctx)) return r;
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->ws.ctl) {
+        uint32_t blocks[RT_MAX_SUBFRAMES * CTL_WORDS];
+        RT_HIP(ctx, hipMemcpy(blocks, ctx->ws.ctl, sizeof blocks, hipMemcpyDeviceToHost));
         uint32_t overflow = 0;
-        RT_HIP(ctx, hipMemcpy(&overflow, static_cast<uint32_t*>(ctx->ws.ctl) + CTL_OVERFLOW, sizeof overflow, hipMemcpyDeviceToHost));
+        for (int i = 0; i < RT_MAX_SUBFRAMES; ++i) overflow |= blocks[i * CTL_WORDS + CTL_OVERFLOW];
         if (overflow)
             return fail(ctx, RT_ERR_LIMIT,
                         "reflection / refraction rays exceeded the path budget of %d x pixels; raise it with rt_set_path_budget",
                         ctx->pathBudget);
     }
+    return RT_OK;
+}
+
+int rt_set_trace_waves(rt_ctx* ctx, int wavesPerCu) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (wavesPerCu < 0 || wavesPerCu > 32) return fail(ctx, RT_ERR_INVALID, "waves per CU must be in 0..32");
+    ctx->maxWavesPerCu = wavesPerCu;
+    return RT_OK;
+}
+
+int rt_set_subframes(rt_ctx* ctx, int count) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (count < 1 || count > RT_MAX_SUBFRAMES) return fail(ctx, RT_ERR_INVALID, "sub-frame count must be in 1..%d", RT_MAX_SUBFRAMES);
+    ctx->subFrames = count;
+    return RT_OK;
+}
+
+int rt_set_lds_stack(rt_ctx* ctx, int entries) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (entries < 1 || entries > RT_STACK_ENTRIES) return fail(ctx, RT_ERR_INVALID, "LDS stack entries must be in 1..%d", RT_STACK_ENTRIES);
+    ctx->ldsStack = entries;
     return RT_OK;
 }
 
@@ -604,33 +670,62 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     p.tilesX = (opts->width + RT_TILE - 1) / RT_TILE;
     p.tilesY = (opts->height + RT_TILE - 1) / RT_TILE;
     const long long tiles = (long long)p.tilesX * p.tilesY;
-    p.tileFirst = aux ? aux->tileFirst : 0;
-    p.tileStride = aux && aux->tileStride > 0 ? aux->tileStride : 1;
-    if (p.tileFirst < 0 || p.tileFirst >= p.tileStride) return fail(ctx, RT_ERR_INVALID, "tileFirst must be in [0, tileStride)");
-    p.tileCnt = (int)((tiles - p.tileFirst + p.tileStride - 1) / p.tileStride);
-    if (p.tileCnt <= 0) return RT_OK;
-    const long long slots = (long long)p.tileCnt * RT_TILE * RT_TILE;
+    const int tileFirst = aux ? aux->tileFirst : 0;
+    const int tileStride = aux && aux->tileStride > 0 ? aux->tileStride : 1;
+    if (tileFirst < 0 || tileFirst >= tileStride) return fail(ctx, RT_ERR_INVALID, "tileFirst must be in [0, tileStride)");
+    const long long myTiles = (tiles - tileFirst + tileStride - 1) / tileStride;
+    if (myTiles <= 0) return RT_OK;
     const int secondary = hd.hasSecondary ? 1 : 0;
-    const long long nodeCap = slots * (secondary && opts->maxDepth > 0 ? ctx->pathBudget : 1);
-    if (nodeCap > 0x7fffffffLL / 4) return fail(ctx, RT_ERR_LIMIT, "frame too large for 32-bit node indices");
-    p.slots = (int)slots;
-    p.nodeCap = (int)nodeCap;
+    const int budget = secondary && opts->maxDepth > 0 ? ctx->pathBudget : 1;
+    if (myTiles * RT_TILE * RT_TILE * budget > 0x7fffffffLL / 4) return fail(ctx, RT_ERR_LIMIT, "frame too large for 32-bit node indices");
     p.stackEntries = hd.sceneDepth + hd.maxMeshDepth + 1;
+    p.stackLds = std::min(p.stackEntries, ctx->ldsStack);
 
     if (int r = bind(ctx)) return r;
-    if (int r = ensureWorkspace(ctx, p.nodeCap, p.slots, hd.lightCnt)) return r;
+    if (ctx->wavesForLds != p.stackLds) {
+        ctx->wavesPerCu = rtk_trace_waves_per_cu(p.stackLds);
+        ctx->wavesForLds = p.stackLds;
+    }
+    p.traceWaves = (ctx->maxWavesPerCu > 0 ? std::min(ctx->wavesPerCu, ctx->maxWavesPerCu) : ctx->wavesPerCu) * ctx->cuCount;
+
+    // Sub-frames: local tile k of this call goes to sub-frame k % nSubs, so every sub-frame
+    // is a regular sample of the same image region and costs about the same.
+    int nSubs = (int)std::min<long long>(std::max(ctx->subFrames, 1), myTiles);
+    FrameParams subs[RT_MAX_SUBFRAMES];
+    long long totalNodes = 0, totalSec = 0;
+    for (int i = 0; i < nSubs; ++i) {
+        FrameParams& q = subs[i];
+        q = p;
+        q.tileFirst = tileFirst + i * tileStride;
+        q.tileStride = tileStride * nSubs;
+        q.tileCnt = (int)((myTiles - i + nSubs - 1) / nSubs);
+        q.slots = q.tileCnt * RT_TILE * RT_TILE;
+        q.nodeCap = q.slots * budget;
+        totalNodes += q.nodeCap;
+        totalSec += q.nodeCap - q.slots;
+    }
+    const size_t spillPerSub = (size_t)p.traceWaves * (size_t)(p.stackEntries - p.stackLds) * 64 * 8;
+    if (int r = ensureWorkspace(ctx, (int)totalNodes, (int)(totalNodes - totalSec), hd.lightCnt, std::max<size_t>(spillPerSub * nSubs, 256))) return r;
     const Workspace& w = ctx->ws;
-    p.ctl = static_cast<uint32_t*>(w.ctl);
-    p.hit = static_cast<float4*>(w.hit);
-    p.hitTri = static_cast<int32_t*>(w.hitTri);
-    p.color = static_cast<float4*>(w.color);
-    p.secRay = static_cast<float4*>(w.secRay);
-    p.child = static_cast<int32_t*>(w.child);
-    p.kr = static_cast<float*>(w.kr);
-    p.kind = static_cast<int32_t*>(w.kind);
-    p.ctx = static_cast<float4*>(w.ctx);
-    p.ctxNode = static_cast<int32_t*>(w.ctxNode);
-    p.vis = static_cast<unsigned char*>(w.vis);
+    const size_t lc = (size_t)std::max(hd.lightCnt, 1);
+    size_t nodeOff = 0, secOff = 0;
+    for (int i = 0; i < nSubs; ++i) {
+        FrameParams& q = subs[i];
+        q.ctl = static_cast<uint32_t*>(w.ctl) + (size_t)i * CTL_WORDS;
+        q.hit = static_cast<float4*>(w.hit) + nodeOff;
+        q.hitTri = static_cast<int32_t*>(w.hitTri) + nodeOff;
+        q.color = static_cast<float4*>(w.color) + nodeOff;
+        q.secRay = static_cast<float4*>(w.secRay) + 2 * secOff;
+        q.child = static_cast<int32_t*>(w.child) + nodeOff;
+        q.kr = static_cast<float*>(w.kr) + nodeOff;
+        q.kind = static_cast<int32_t*>(w.kind) + nodeOff;
+        q.ctx = static_cast<float4*>(w.ctx) + 4 * nodeOff;
+        q.ctxNode = static_cast<int32_t*>(w.ctxNode) + nodeOff;
+        q.vis = static_cast<unsigned char*>(w.vis) + nodeOff * lc;
+        q.stackSpill = reinterpret_cast<uint2*>(static_cast<unsigned char*>(w.stackSpill) + spillPerSub * i);
+        nodeOff += (size_t)q.nodeCap;
+        secOff += (size_t)(q.nodeCap - q.slots);
+    }
 
     if (ctx->launchesUsed == ctx->launches.size()) {
         if (ctx->launches.size() >= 65536) return fail(ctx, RT_ERR_LIMIT, "call rt_timing_reset: too many timed launches");
@@ -639,7 +734,9 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
         ctx->launches.push_back(l);
     }
     TimedLaunch& l = ctx->launches[ctx->launchesUsed];
-    hipError_t e = (hipError_t)rtk_render_frame(&p, secondary, p.counters ? 1 : 0, ctx->cuCount, ctx->stream, reinterpret_cast<void**>(l.ev));
+    hipError_t e = (hipError_t)rtk_render_frame(subs, nSubs, secondary, p.counters ? 1 : 0, ctx->cuCount, ctx->stream,
+                                                reinterpret_cast<void**>(ctx->subStreams), reinterpret_cast<void**>(ctx->subEvents),
+                                                reinterpret_cast<void**>(l.ev));
     if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
     ctx->launchesUsed++;
     return RT_OK;

@@ -153,7 +153,9 @@ struct FrameParams {
     int32_t tileFirst, tileStride, tileCnt;  // this call renders tiles tileFirst + k*tileStride, k < tileCnt
     int32_t slots;                           // tileCnt * 64 level-0 nodes
     int32_t nodeCap;                         // capacity of the per-node arrays
-    int32_t stackEntries;                    // per-lane traversal stack entries in LDS (8 bytes each)
+    int32_t stackEntries;                    // per-lane traversal stack entries needed (8 bytes each)
+    int32_t stackLds;                        // how many of them live in LDS; the rest in stackSpill
+    int32_t traceWaves;                      // wavefronts of the persistent trace kernels
     // workspace (device pointers)
     uint32_t* ctl;          // CTL_WORDS
     float4* hit;            // [nodeCap] {t, u, v, shape slot as int bits (-1 miss, -2 outside the frame)}
@@ -166,12 +168,21 @@ struct FrameParams {
     float4* ctx;            // [4 * nodeCap] shading context of each diffuse hit of the current level
     int32_t* ctxNode;       // [nodeCap] node of each diffuse hit
     unsigned char* vis;     // [nodeCap * max(lightCnt,1)] 1 = light visible
+    uint2* stackSpill;      // [traceWaves * (stackEntries - stackLds) * 64] deep stack entries
 };
 
-// Enqueues all kernels of one frame on `stream` (no host synchronisation).
-// `stageEvents`: optional hipEvent_t[5] recorded at frame start, after the
-// level-0 closest-hit trace, after shading, after the shadow trace, at frame end.
-// Returns a hipError_t value.
-int rtk_render_frame(const FrameParams* p, int hasSecondary, int count, int cuCount, void* stream, void** stageEvents);
+#define RT_MAX_SUBFRAMES 8
+
+// Enqueues all kernels of one frame (no host synchronisation).  The frame is given as nSubs
+// sub-frames (disjoint tile sets with their own workspace slices and control blocks); with
+// nSubs > 1 they run concurrently on subStreams[] (subEvents = hipEvent_t[1 + nSubs] for the
+// fork and the joins) and are joined back into `stream`.
+// `stageEvents`: optional hipEvent_t[5] recorded at frame start, after the level-0 closest-hit
+// trace, after shading, after the shadow trace (these three only split the time when nSubs == 1),
+// at frame end.  Returns a hipError_t value.
+int rtk_render_frame(const FrameParams* subs, int nSubs, int hasSecondary, int count, int cuCount, void* stream, void** subStreams,
+                     void** subEvents, void** stageEvents);
+// Resident wavefronts per CU of the trace kernels for a given LDS stack size.
+int rtk_trace_waves_per_cu(int stackLds);
 
 #endif

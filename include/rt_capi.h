@@ -185,7 +185,11 @@ enum {
     RT_CNT_MESH_ENTRY = 6,/* ray -> object-space transforms                  */
     RT_CNT_SHADE_MESH = 7,/* shaded mesh hits                                */
     RT_CNT_SHADE_SPHERE = 8,
-    RT_COUNTER_CNT = 16
+    /* wave-step statistics of the trace kernels (diagnostics; six words each):
+     * steps, node steps, lanes in node steps, triangle steps, lanes in triangle steps, lanes holding a ray */
+    RT_CNT_STAT_CLOSEST = 16,
+    RT_CNT_STAT_SHADOW = 22,
+    RT_COUNTER_CNT = 32
 };
 typedef struct RtFrameAux {
     int32_t* hitKeys;
@@ -270,6 +274,22 @@ int rt_timing_read_stages(rt_ctx* ctx, double* totalMs, double* stageMs, int* la
  * per-frame node arrays hold `nodesPerPixel` x pixels path nodes (default 3).
  * A frame that needs more reports RT_ERR_LIMIT from rt_sync. */
 int rt_set_path_budget(rt_ctx* ctx, int nodesPerPixel);
+
+/* Tuning knob: how many traversal-stack entries per ray are kept in LDS (8 bytes
+ * each, 64 rays per wavefront); deeper entries go to a global spill array.
+ * Fewer entries = more resident wavefronts per CU.  Results do not depend on it. */
+int rt_set_lds_stack(rt_ctx* ctx, int entries);
+
+/* Tuning knob: rt_render splits its tiles into `count` interleaved sub-frames that
+ * run concurrently on internal streams (joined before the call's work is complete
+ * on the context's stream), so that the draining tail of one persistent trace
+ * kernel overlaps with other work.  1 = plain single-stream order.  Results do
+ * not depend on it. */
+int rt_set_subframes(rt_ctx* ctx, int count);
+
+/* Tuning knob: upper bound on persistent trace wavefronts per CU (0 = as many as
+ * the hardware keeps resident).  Results do not depend on it. */
+int rt_set_trace_waves(rt_ctx* ctx, int wavesPerCu);
 
 /* cu_initCurand / cu_cleanCurand (cudaTracer/Main.cu:113-150) have no
  * counterpart: samples == 1 draws no random numbers. */

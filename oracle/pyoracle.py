@@ -64,7 +64,7 @@ def render(desc, opts, camera, width, height, rows=None, threads=1, shadow_any_h
     lib = load()
     rgba = np.zeros((height, width, 4), dtype=np.float32)
     keys = np.full((height, width, 4), -1, dtype=np.int32) if want_keys else None
-    cnt = np.zeros(16, dtype=np.uint64) if want_counters else None
+    cnt = np.zeros(32, dtype=np.uint64) if want_counters else None
     y0, y1, ys = rows if rows else (0, height, 1)
     rc = lib.oracle_render(_addr(desc), _addr(opts), _addr(camera), rgba.ctypes.data, keys.ctypes.data if want_keys else None,
                            cnt.ctypes.data if want_counters else None, y0, y1, ys, threads, 1 if shadow_any_hit else 0)

@@ -20,20 +20,33 @@ ap.add_argument("--lights", type=int, default=1)
 ap.add_argument("--max-depth", type=int, default=0)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--reference-bvh", action="store_true")
+ap.add_argument("--lds-stack", type=int, default=0)
+ap.add_argument("--subframes", type=int, default=0)
+ap.add_argument("--waves", type=int, default=0)
 a = ap.parse_args()
 
 t = time.time()
 scene = rt.HostScene(a.scene, a.width, a.height, a.size, a.lights, a.max_depth, tight_bvh=not a.reference_bvh)
 print(f"scene {a.scene} size {a.size}: built in {time.time()-t:.2f}s, depth {scene.bvh_depth()}", flush=True)
 with rt.Context(0) as ctx:
+    if a.waves:
+        ctx.set_trace_waves(a.waves)
+    if a.subframes:
+        ctx.set_subframes(a.subframes)
+    if a.lds_stack:
+        ctx.set_lds_stack(a.lds_stack)
     ds = ctx.upload(scene)
     surf, pitch = ctx.surface(a.width, a.height)
     cnt = ctx.alloc(rt.RT_COUNTER_CNT * 8)
     ctx.render(ds, scene.opts, scene.camera, surf, pitch, None, cnt)
     ctx.sync()
     import numpy as np
-    c = ctx.download(cnt, (rt.RT_COUNTER_CNT,), np.uint64)
-    c = {n: int(c[i]) for i, n in enumerate(rt.RT_COUNTER_NAMES)}
+    raw = ctx.download(cnt, (rt.RT_COUNTER_CNT,), np.uint64)
+    c = {n: int(raw[i]) for i, n in enumerate(rt.RT_COUNTER_NAMES)}
+    for name, b in (("closest", 16), ("shadow", 22)):
+        st = [int(v) for v in raw[b:b + 6]]
+        if st[0]:
+            print(f"  {name}: wave-steps {st[0]}  node-steps {st[1]} (avg lanes {st[2]/max(st[1],1):.1f})  tri-steps {st[3]} (avg lanes {st[4]/max(st[3],1):.1f})  avg lanes with a ray {st[5]/st[0]:.1f}")
     rays = c["primary"] + c["shadow"] + c["secondary"]
     for _ in range(2):
         ctx.render(ds, scene.opts, scene.camera, surf, pitch)
