@@ -1,0 +1,121 @@
+"""Host BVH builder (BVH::BvhFactory) against the oracle's restatement of
+cudaTracer/BVH.h, and BVH-independent properties of the traced image."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cudaraytracer_amd as rt
+from cudaraytracer_amd import _native as N
+
+
+def random_mesh(n_tris, seed, lo=-5.0, hi=5.0, coincident=0):
+    rng = np.random.default_rng(seed)
+    verts = (N.RtVertex * (3 * n_tris))()
+    tris = (N.RtTriangle * n_tris)()
+    for t in range(n_tris):
+        c = rng.uniform(lo, hi, 3) if t >= coincident else np.array([1.0, 2.0, 3.0])
+        for k in range(3):
+            p = c + (rng.uniform(-0.5, 0.5, 3) if t >= coincident else np.array([0.1 * k, 0.0, 0.1 * (k == 2)]))
+            for a in range(3):
+                verts[3 * t + k].position[a] = float(np.float32(p[a]))
+            tris[t].i[k] = 3 * t + k
+    return verts, tris
+
+
+def build_both(rtlib, oracle, verts, tris, threshold, tight):
+    n = len(tris)
+    out = {}
+    for name in ("host", "oracle"):
+        nodes = (N.RtLinearNode * (2 * n))()
+        cnt = C.c_int()
+        order = (C.c_int * n)()
+        if name == "host":
+            rc = rtlib.rth_bvh_triangles(verts, len(verts), tris, n, threshold, tight, nodes, C.byref(cnt), order)
+        else:
+            rc = oracle.load().oracle_bvh_triangles(C.addressof(verts), C.addressof(tris), n, threshold, tight, C.addressof(nodes), C.byref(cnt), C.addressof(order))
+        assert rc == 0
+        out[name] = (bytes(nodes)[: 32 * cnt.value], list(order), cnt.value)
+    return out
+
+
+@pytest.mark.parametrize("n,threshold,tight,lo,hi", [(1, 10, 0, -5, 5), (7, 10, 0, -5, 5), (11, 10, 0, -5, 5), (500, 10, 0, -5, 5),
+                                                      (500, 10, 1, -5, 5), (2000, 4, 1, -50, 50), (333, 1, 0, 1, 9), (1000, 10, 0, -9, -1)])
+def test_host_builder_equals_oracle_builder(rtlib, oracle, n, threshold, tight, lo, hi):
+    verts, tris = random_mesh(n, seed=n + threshold, lo=lo, hi=hi)
+    r = build_both(rtlib, oracle, verts, tris, threshold, tight)
+    assert r["host"][2] == r["oracle"][2]
+    assert r["host"][1] == r["oracle"][1], "leaf order differs"
+    assert r["host"][0] == r["oracle"][0], "node bytes differ"
+    assert sorted(r["host"][1]) == list(range(n))
+
+
+def test_equal_count_split_makes_a_balanced_tree(rtlib, oracle):
+    verts, tris = random_mesh(1000, seed=5)
+    nodes_b, order, cnt = build_both(rtlib, oracle, verts, tris, 10, 1)["host"]
+    nodes = np.frombuffer(nodes_b, dtype=np.uint8).reshape(cnt, 32)
+    prim_cnt = nodes[:, 28:30].copy().view(np.uint16)[:, 0]
+    leaves = prim_cnt[prim_cnt > 0]
+    assert leaves.sum() == 1000 and leaves.max() <= 10
+    assert cnt == 2 * len(leaves) - 1  # full binary tree
+    assert len(leaves) == 128  # 1000 -> halves until <= 10: 2^7 leaves of 7-8 triangles
+
+
+def test_coincident_centroids_become_one_leaf(rtlib, oracle):
+    # BVH.h:126-128: no spread of the centroids along the chosen axis -> leaf, whatever the count
+    verts, tris = random_mesh(40, seed=3, coincident=40)
+    r = build_both(rtlib, oracle, verts, tris, 10, 0)
+    assert r["host"] == r["oracle"]
+    assert r["host"][2] == 1
+
+
+def test_reference_bounds_are_clamped_at_flt_min(rtlib, oracle):
+    """BoundingBox.cuh:25-27: the empty box's max corner is FLT_MIN, so all-negative geometry gets boxes reaching ~0."""
+    verts, tris = random_mesh(64, seed=9, lo=-9, hi=-1)
+    ref = np.frombuffer(build_both(rtlib, oracle, verts, tris, 10, 0)["host"][0], dtype=np.float32).reshape(-1, 8)
+    tight = np.frombuffer(build_both(rtlib, oracle, verts, tris, 10, 1)["host"][0], dtype=np.float32).reshape(-1, 8)
+    flt_min = np.finfo(np.float32).tiny
+    assert np.all(ref[:, 3:6] == flt_min)
+    assert np.all(tight[:, 3:6] < 0)
+
+
+@pytest.mark.parametrize("name,size", [("cubes", 6), ("soup", 3000), ("mixed", 0)])
+def test_image_does_not_depend_on_the_bvh(oracle, name, size):
+    """Tight vs reference bounds, and BVH vs linear scans (useSceneBvh / useMeshBvhs off), give the same hits."""
+    w, h = 64, 40
+    frames = []
+    for tight in (False, True):
+        s = rt.HostScene(name, w, h, size, 2, 2, tight_bvh=tight)
+        frames.append(oracle.render(s.desc, s.opts, s.camera, w, h, threads=4)[:2])
+    s = rt.HostScene(name, w, h, size, 2, 2, tight_bvh=True)
+    s.opts.contents.useSceneBvh = 0
+    s.opts.contents.useMeshBvhs = 0
+    frames.append(oracle.render(s.desc, s.opts, s.camera, w, h, threads=4)[:2])
+    for rgba, keys in frames[1:]:
+        assert np.array_equal(keys, frames[0][1])
+        assert np.array_equal(rgba, frames[0][0], equal_nan=True)
+
+
+def test_any_hit_shadow_rays_give_the_same_image(oracle):
+    s = rt.HostScene("mixed", 80, 60, 0, 5, 3)
+    a = oracle.render(s.desc, s.opts, s.camera, 80, 60, threads=4, shadow_any_hit=False)
+    b = oracle.render(s.desc, s.opts, s.camera, 80, 60, threads=4, shadow_any_hit=True)
+    assert np.array_equal(a[0], b[0], equal_nan=True) and np.array_equal(a[1], b[1])
+    assert b[2]["node"] < a[2]["node"]  # fewer tests, same booleans
+
+
+def test_matrix_inverse_host_equals_oracle(rtlib, oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(50):
+        m = rng.uniform(-3, 3, 16).astype(np.float32)
+        a = (C.c_float * 16)(*m)
+        o1 = (C.c_float * 16)()
+        o2 = (C.c_float * 16)()
+        rtlib.rth_mat_inverse(a, o1)
+        oracle.load().oracle_mat_inverse(a, o2)
+        assert bytes(o1) == bytes(o2)
+    ident = (C.c_float * 16)(*np.eye(4, dtype=np.float32).ravel())
+    sing = (C.c_float * 16)(*np.zeros(16, dtype=np.float32))
+    out = (C.c_float * 16)()
+    rtlib.rth_mat_inverse(sing, out)  # singular -> identity (Mat.cuh:193-196)
+    assert bytes(out) == bytes(ident)
