@@ -53,30 +53,34 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(scene, args, rays_per_pixel):
-    """The CPU restatement timed on this host, on every k-th row of the same frame."""
+def cpu_baseline(scene, args):
+    """The CPU restatement timed on this host: whole frames of the same workload, repeated until ~cpu_seconds have passed."""
     from oracle import pyoracle
 
     threads = max(1, min(16, os.cpu_count() or 1))
     w, h = args.width, args.height
-    # calibrate on a thin sample, then size the real sample for ~cpu_seconds
-    step0 = max(1, h // 8)
-    t0 = time.perf_counter()
-    pyoracle.render(scene.desc, scene.opts, scene.camera, w, h, rows=(0, h, step0), threads=threads, shadow_any_hit=True,
-                    want_keys=False, want_counters=False)
-    dt0 = time.perf_counter() - t0
-    rows0 = len(range(0, h, step0))
-    per_row = dt0 / rows0
-    want_rows = int(min(h, max(rows0, args.cpu_seconds / max(per_row, 1e-9))))
-    step = max(1, h // want_rows)
-    t0 = time.perf_counter()
-    _, _, cnt = pyoracle.render(scene.desc, scene.opts, scene.camera, w, h, rows=(0, h, step), threads=threads, shadow_any_hit=True,
-                                want_keys=False, want_counters=True)
-    dt = time.perf_counter() - t0
-    rays = cnt["primary"] + cnt["shadow"]
+    frames, rays, dt = 0, 0, 0.0
+    while dt < args.cpu_seconds and frames < 1000:
+        t0 = time.perf_counter()
+        _, _, cnt = pyoracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=threads, shadow_any_hit=True,
+                                    want_keys=False, want_counters=True)
+        dt += time.perf_counter() - t0
+        rays += cnt["primary"] + cnt["shadow"]
+        frames += 1
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": f"every {step}th row of the {w}x{h} frame ({len(range(0, h, step))} rows, {rays} rays, {dt:.1f} s), "
-                      f"-O2 -ffp-contract=off, any-hit shadow rays, same BVH as the GPU run"}
+            "sample": f"{frames} full {w}x{h} frame(s) of the same scene ({rays} rays, {dt:.1f} s), rows interleaved over {threads} threads, "
+                      f"gcc -O2 -ffp-contract=off, any-hit shadow rays, same BVH as the GPU run"}
+
+
+def pmc_traffic(kernel, workload_key):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        table = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    entry = table.get(workload_key, {}).get(kernel)
+    return None if entry is None else entry.get("hbm_bytes_per_launch")
 
 
 def main():
@@ -111,30 +115,23 @@ def main():
         scene = rt.HostScene(args.scene, w, h, args.size, args.lights, args.max_depth, tight_bvh=not args.reference_bvh)
     t_build = time.perf_counter() - t_build
     if multi:
-        meta = torch.zeros(1 + 12 + 3 + 16, dtype=torch.float64, device=dev)
-        opts_bytes = torch.zeros(48, dtype=torch.uint8, device=dev)
+        from cudaraytracer_amd import multi as mg
+
+        blob0 = opts0 = cam0 = None
         if rank == 0:
-            blob_host = ctx.pack(scene.desc)
-            blob = torch.from_numpy(blob_host).to(dev)
-            meta[0] = blob.numel()
+            blob0 = torch.from_numpy(ctx.pack(scene.desc)).to(dev)
+            opts0 = bytes(scene.opts.contents)
             cam = scene.camera.contents
-            meta[13:16] = torch.tensor(list(cam.orig), dtype=torch.float64)
-            meta[16:32] = torch.tensor(list(cam.camera), dtype=torch.float64)
-            opts_bytes.copy_(torch.frombuffer(bytearray(bytes(scene.opts.contents)), dtype=torch.uint8))
-        dist.broadcast(meta, 0)
-        dist.broadcast(opts_bytes, 0)
-        if rank != 0:
-            blob = torch.empty(int(meta[0].item()), dtype=torch.uint8, device=dev)
-        dist.broadcast(blob, 0)  # RCCL over xGMI: the whole scene + BVH, once
+            cam0 = list(cam.orig) + list(cam.camera)
+        blob, opts_raw, cam_f = mg.share_scene(blob0, opts0, cam0, rank, world, dev)  # RCCL over xGMI: scene + BVH, once
         torch.cuda.synchronize(dev)
         dscene = ctx.adopt_blob(blob.data_ptr(), blob.numel())
-        opts = rt.RtDeviceOpts.from_buffer_copy(bytes(opts_bytes.cpu().numpy().tobytes()))
+        opts = rt.RtDeviceOpts.from_buffer_copy(opts_raw)
         camera = rt.RtCamera()
-        m = meta.cpu().numpy()
         for i in range(3):
-            camera.orig[i] = float(np.float32(m[13 + i]))
+            camera.orig[i] = float(cam_f[i])
         for i in range(16):
-            camera.camera[i] = float(np.float32(m[16 + i]))
+            camera.camera[i] = float(cam_f[3 + i])
         camera_ref = C.byref(camera)
     else:
         dscene = ctx.upload(scene)
@@ -144,33 +141,12 @@ def main():
     # ---- frame buffers (torch owns the memory; the library gets raw pointers) ----
     surface = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
     pitch = w * 16
-    tiles_x, tiles_y = (w + 7) // 8, (h + 7) // 8
-    can_tile_view = (w % 8 == 0) and (h % 8 == 0)
-    if multi and not can_tile_view:
-        raise SystemExit("multi-GPU bench needs a frame size divisible by 8")
-    my_tiles = torch.arange(rank, tiles_x * tiles_y, world, device=dev)
-    gather_list = None
-    if multi and rank == 0:
-        gather_list = [torch.empty((len(range(r, tiles_x * tiles_y, world)), 8, 8, 4), dtype=torch.float32, device=dev)
-                       for r in range(world)]
-        final = torch.zeros((tiles_y, tiles_x, 8, 8, 4), dtype=torch.float32, device=dev)
+    gatherer = mg.TileGather(w, h, rank, world, dev) if multi else None
 
     def step():
         ctx.render(dscene, opts, camera_ref, surface.data_ptr(), pitch, None, None, rank, world)
         if multi:
-            tiles = surface.view(tiles_y, 8, tiles_x, 8, 4).permute(0, 2, 1, 3, 4).reshape(tiles_x * tiles_y, 8, 8, 4)
-            mine = tiles.index_select(0, my_tiles)
-            if rank == 0:
-                # rank 0 keeps its own tiles in place; peers send theirs
-                reqs = [dist.irecv(gather_list[r], src=r) for r in range(1, world)]
-                for q in reqs:
-                    q.wait()
-                flat = final.view(tiles_x * tiles_y, 8, 8, 4)
-                flat[rank::world] = mine
-                for r in range(1, world):
-                    flat[r::world] = gather_list[r]
-            else:
-                dist.send(mine, dst=0)
+            gatherer.gather(surface)
 
     # ---- exact ray / test counts of the frame (untimed counter build) ----
     cnt_buf = torch.zeros(rt.RT_COUNTER_CNT, dtype=torch.int64, device=dev)
@@ -196,17 +172,31 @@ def main():
         dist.barrier()
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    kernel_ms, launches = ctx.timing_read()
+    kernel_ms, stages, launches = ctx.timing_read_stages()
+    launches = max(launches, 1)
+    # per-stage averages measured with HIP events on the library's stream: [closest-hit trace, shade, shadow trace, rest]
+    t_stage = [kernel_ms / launches] + [x / launches for x in stages]
     if multi:
-        t = torch.tensor([elapsed, kernel_ms / max(launches, 1)], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed] + t_stage, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_avg_ms = float(t[0].item()), float(t[1].item())
-    else:
-        kernel_avg_ms = kernel_ms / max(launches, 1)
+        elapsed, t_stage = float(t[0].item()), [float(x) for x in t[1:].tolist()]
+    frame_ms, closest_ms, shade_ms, shadow_ms, rest_ms = t_stage
 
     if rank == 0:
-        alg_bytes = algorithmic_bytes(cnt, w * h)  # whole frame; one launch per GPU handles 1/N of it
-        achieved = alg_bytes / world / (kernel_avg_ms * 1e-3) / 1e9
+        raw = [int(x) for x in cnt_buf.tolist()]
+        sh = dict(zip(("node", "tri", "sphere", "mesh_entry"), raw[9:13]))
+        closest = {k: cnt[k] - sh[k] for k in sh}
+        # algorithmic bytes of the dominant launch: the closest-hit trace of the primary rays (one launch per frame
+        # when maxDepth is 0) reads 32 B per box test, 48 B per triangle test, 20 B per sphere test, 64 B per mesh
+        # entry, and writes 20 B of hit record per ray; with N GPUs one launch handles 1/N of the frame
+        closest_bytes = (NODE_BYTES * closest["node"] + TRI_BYTES * closest["tri"] + SPHERE_BYTES * closest["sphere"] +
+                         MESH_ENTRY_BYTES * closest["mesh_entry"] + 20 * (cnt["primary"] + cnt["secondary"]))
+        shadow_bytes = (NODE_BYTES * sh["node"] + TRI_BYTES * sh["tri"] + SPHERE_BYTES * sh["sphere"] + MESH_ENTRY_BYTES * sh["mesh_entry"] +
+                        (64 + 1) * cnt["shadow"])
+        frame_bytes = algorithmic_bytes(cnt, w * h)
+        gbs = lambda b, ms: b / world / (ms * 1e-3) / 1e9 if ms > 0 else None
+        achieved = gbs(closest_bytes, closest_ms)
+        wl_key = f"{args.scene}-{args.size}-{w}x{h}-l{args.lights}-d{args.max_depth}"
         out = {
             "metric": "Mrays/s (primary+shadow) at 1080p, 1M tris",
             "value": rays * args.steps / elapsed / 1e6,
@@ -226,16 +216,21 @@ def main():
                        "rays_per_frame": rays, "primary": cnt["primary"], "shadow": cnt["shadow"],
                        "tile_sharding": f"8x8 tiles, tile t on GPU t % {world}, gathered to GPU0 each frame" if multi else "single GPU",
                        "scene_build_s": round(t_build, 2)},
-            "kernel_ms": kernel_avg_ms,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
-                         "note": "algorithmic bytes = 32/node test + 48/triangle test + 64/mesh entry + 216/shaded mesh hit + 16/pixel, "
-                                 "test counts exact from the kernel's counter build; the 56 MB BVH + records are cache-resident, so this "
-                                 "path is latency/VALU-bound, not HBM-bound",
+            "kernel_ms": {"frame": frame_ms, "trace_closest": closest_ms, "shade": shade_ms, "trace_shadow": shadow_ms, "rest": rest_ms},
+            "roofline": {"bound": "hbm", "kernel": "traceKernel<false,false> (closest hit, primary rays)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic("traceKernel<false, false>", wl_key),
+                         "algorithmic_bytes_per_launch": closest_bytes // world,
+                         "other_kernels": {"traceKernel<true,false> (shadow, any hit)": {"achieved": gbs(shadow_bytes, shadow_ms),
+                                                                                         "algorithmic_bytes_per_launch": shadow_bytes // world},
+                                           "whole frame": {"achieved": gbs(frame_bytes, frame_ms), "algorithmic_bytes": frame_bytes // world}},
+                         "note": "algorithmic bytes = 32/box test + 48/triangle test + 20/sphere test + 64/mesh entry + 20/ray hit record, "
+                                 "test counts exact from the counter build of the same kernels; duration from HIP events on the launch stream. "
+                                 "The BVH and triangle records (about 100 MB) stay L2 / Infinity-Cache resident, so HBM is the nominal bound only",
                          "tests_per_ray": {"node": cnt["node"] / rays, "tri": cnt["tri"] / rays}},
         }
         if not args.no_cpu and args.cpu_seconds > 0 and not multi:
-            out["cpu_baseline"] = cpu_baseline(scene, args, rays / (w * h))
+            out["cpu_baseline"] = cpu_baseline(scene, args)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -128,6 +128,8 @@ HARNESS = {
     "rth_read_png": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rth_bvh_triangles": (C.c_int, [C.POINTER(RtVertex), C.c_int, C.POINTER(RtTriangle), C.c_int, C.c_int, C.c_int,
                                     C.POINTER(RtLinearNode), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rth_obj_read": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(RtVertex), C.c_int, C.POINTER(C.c_int), C.c_int,
+                               C.c_char_p, C.c_int]),
     "rth_mat_inverse": (None, [C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rth_selftest": (C.c_int, [C.c_char_p, C.c_int]),
 }

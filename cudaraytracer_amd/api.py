@@ -85,6 +85,18 @@ def tiles_of_rank(width, height, rank, world, tile=8):
     return np.arange(rank, tx * ty, world, dtype=np.int64), tx, ty
 
 
+def pack_scene(lib, desc, ctx=None):
+    """rt_scene_pack: flattens a scene description into the relocatable device blob on the host (needs no GPU)."""
+    p, n = C.c_void_p(), C.c_size_t()
+    rc = lib.rt_scene_pack(ctx, desc, C.byref(p), C.byref(n))
+    if rc != 0:
+        raise RtError(f"rt_scene_pack failed ({rc}): {lib.rt_last_error(ctx).decode()}")
+    try:
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_ubyte)), shape=(n.value,)).copy()
+    finally:
+        lib.rt_blob_free(p)
+
+
 class Context:
     """One GPU. Owns device-side scenes, surfaces and aux buffers via the C-ABI."""
 
@@ -140,12 +152,7 @@ class Context:
 
     def pack(self, desc):
         """Host-side flattening only: returns the blob as a numpy uint8 array."""
-        p, n = C.c_void_p(), C.c_size_t()
-        self._check(self.lib.rt_scene_pack(self.ctx, desc, C.byref(p), C.byref(n)), "rt_scene_pack")
-        try:
-            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_ubyte)), shape=(n.value,)).copy()
-        finally:
-            self.lib.rt_blob_free(p)
+        return pack_scene(self.lib, desc, self.ctx)
 
     def set_lights(self, scene, desc):
         d = desc.contents if hasattr(desc, "contents") else desc

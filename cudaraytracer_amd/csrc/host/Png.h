@@ -1,8 +1,9 @@
 // Minimal PNG codec on zlib: decode to RGBA8 (what the reference gets from
 // lodepng::decode, cudaTracer/CudaMesh.h:85-104) and encode RGBA8 (what
-// lodepng::encode writes for cudaTracer/PicDumper.h:39).  Supports
-// non-interlaced images, bit depth 8 or 16, colour types grey, grey+alpha, RGB,
-// RGBA and 8-bit palette (with tRNS).
+// lodepng::encode writes for cudaTracer/PicDumper.h:39).  Decodes every
+// standard colour type and bit depth (grey 1-16, RGB, palette 1-8, grey+alpha,
+// RGBA), tRNS transparency and Adam7 interlacing; 16-bit samples keep their
+// high byte.
 #ifndef RT_HOST_PNG_H
 #define RT_HOST_PNG_H
 
@@ -57,8 +58,7 @@ inline bool decodeMemory(const std::vector<unsigned char>& file, std::vector<uns
         pos += 12 + (size_t)len;
     }
     if (!haveHeader || width == 0 || height == 0) return fail("missing IHDR");
-    if (interlace != 0) return fail("interlaced PNG not supported");
-    if (bitDepth != 8 && bitDepth != 16) return fail("bit depth not supported");
+    if (interlace > 1) return fail("bad interlace method");
     unsigned channels;
     switch (colorType) {
         case 0: channels = 1; break;
@@ -68,60 +68,109 @@ inline bool decodeMemory(const std::vector<unsigned char>& file, std::vector<uns
         case 6: channels = 4; break;
         default: return fail("bad colour type");
     }
-    if (colorType == 3 && bitDepth != 8) return fail("palette depth not supported");
-    const size_t bpp = channels * (bitDepth / 8);
-    const size_t stride = (size_t)width * bpp;
-    std::vector<unsigned char> raw((stride + 1) * height);
-    uLongf rawLen = (uLongf)raw.size();
-    if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size())
-        return fail("inflate failed");
-    // undo the per-row filters in place
-    std::vector<unsigned char> prev(stride, 0);
-    for (unsigned y = 0; y < height; ++y) {
-        unsigned char* row = &raw[y * (stride + 1)];
-        const unsigned filter = row[0];
-        unsigned char* cur = row + 1;
-        for (size_t i = 0; i < stride; ++i) {
-            const int a = i >= bpp ? cur[i - bpp] : 0;
-            const int b = prev[i];
-            const int c = i >= bpp ? prev[i - bpp] : 0;
-            int pred = 0;
-            switch (filter) {
-                case 0: pred = 0; break;
-                case 1: pred = a; break;
-                case 2: pred = b; break;
-                case 3: pred = (a + b) / 2; break;
-                case 4: {
-                    const int p = a + b - c;
-                    const int pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-                    break;
-                }
-                default: return fail("bad filter");
-            }
-            cur[i] = (unsigned char)(cur[i] + pred);
+    const bool depthOk = (colorType == 0) ? (bitDepth == 1 || bitDepth == 2 || bitDepth == 4 || bitDepth == 8 || bitDepth == 16)
+                       : (colorType == 3) ? (bitDepth == 1 || bitDepth == 2 || bitDepth == 4 || bitDepth == 8)
+                                          : (bitDepth == 8 || bitDepth == 16);
+    if (!depthOk) return fail("bit depth not allowed for this colour type");
+    const size_t bitsPerPixel = (size_t)channels * bitDepth;
+    const size_t bpp = bitsPerPixel >= 8 ? bitsPerPixel / 8 : 1;  // filter distance in bytes
+
+    // passes: the whole image, or the seven Adam7 sub-images
+    struct Pass { unsigned x0, y0, dx, dy, w, h; };
+    std::vector<Pass> passes;
+    if (interlace == 0) {
+        passes.push_back({0, 0, 1, 1, width, height});
+    } else {
+        static const unsigned X0[7] = {0, 4, 0, 2, 0, 1, 0}, Y0[7] = {0, 0, 4, 0, 2, 0, 1};
+        static const unsigned DX[7] = {8, 8, 4, 4, 2, 2, 1}, DY[7] = {8, 8, 8, 4, 4, 2, 2};
+        for (int i = 0; i < 7; ++i) {
+            const unsigned w = (width + DX[i] - 1 - X0[i]) / DX[i], h = (height + DY[i] - 1 - Y0[i]) / DY[i];
+            if (width > X0[i] && height > Y0[i] && w && h) passes.push_back({X0[i], Y0[i], DX[i], DY[i], w, h});
         }
-        std::memcpy(prev.data(), cur, stride);
     }
-    rgba.resize((size_t)width * height * 4);
-    const size_t step = bitDepth / 8;  // 16-bit samples: keep the high byte
-    for (unsigned y = 0; y < height; ++y) {
-        const unsigned char* cur = &raw[y * (stride + 1) + 1];
-        for (unsigned x = 0; x < width; ++x) {
-            const unsigned char* s = cur + x * bpp;
-            unsigned char* d = &rgba[((size_t)y * width + x) * 4];
-            switch (colorType) {
-                case 0: d[0] = d[1] = d[2] = s[0]; d[3] = 255; break;
-                case 2: d[0] = s[0]; d[1] = s[step]; d[2] = s[2 * step]; d[3] = 255; break;
-                case 3: {
-                    const unsigned idx = s[0];
-                    if ((idx + 1) * 3 > palette.size()) return fail("palette index");
-                    d[0] = palette[idx * 3]; d[1] = palette[idx * 3 + 1]; d[2] = palette[idx * 3 + 2];
-                    d[3] = idx < trns.size() ? trns[idx] : 255;
-                    break;
+    size_t rawSize = 0;
+    for (const Pass& ps : passes) rawSize += (((size_t)ps.w * bitsPerPixel + 7) / 8 + 1) * ps.h;
+    std::vector<unsigned char> raw(rawSize);
+    uLongf rawLen = (uLongf)raw.size();
+    if (idat.empty() || uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size())
+        return fail("inflate failed");
+
+    rgba.assign((size_t)width * height * 4, 0);
+    const unsigned maxVal = (1u << (bitDepth < 8 ? bitDepth : 8)) - 1u;
+    size_t at = 0;
+    for (const Pass& ps : passes) {
+        const size_t stride = ((size_t)ps.w * bitsPerPixel + 7) / 8;
+        std::vector<unsigned char> prev(stride, 0);
+        for (unsigned y = 0; y < ps.h; ++y) {
+            unsigned char* row = &raw[at];
+            at += stride + 1;
+            const unsigned filter = row[0];
+            unsigned char* cur = row + 1;
+            for (size_t i = 0; i < stride; ++i) {
+                const int a = i >= bpp ? cur[i - bpp] : 0;
+                const int b = prev[i];
+                const int c = i >= bpp ? prev[i - bpp] : 0;
+                int pred = 0;
+                switch (filter) {
+                    case 0: pred = 0; break;
+                    case 1: pred = a; break;
+                    case 2: pred = b; break;
+                    case 3: pred = (a + b) / 2; break;
+                    case 4: {
+                        const int p = a + b - c;
+                        const int pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                        pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                        break;
+                    }
+                    default: return fail("bad filter");
                 }
-                case 4: d[0] = d[1] = d[2] = s[0]; d[3] = s[step]; break;
-                case 6: d[0] = s[0]; d[1] = s[step]; d[2] = s[2 * step]; d[3] = s[3 * step]; break;
+                cur[i] = (unsigned char)(cur[i] + pred);
+            }
+            std::memcpy(prev.data(), cur, stride);
+            for (unsigned x = 0; x < ps.w; ++x) {
+                unsigned char* d = &rgba[((size_t)(ps.y0 + y * ps.dy) * width + (ps.x0 + x * ps.dx)) * 4];
+                if (bitDepth < 8) {  // grey or palette, packed most significant bit first
+                    const size_t bit = (size_t)x * bitDepth;
+                    const unsigned v = (cur[bit >> 3] >> (8 - bitDepth - (bit & 7))) & maxVal;
+                    if (colorType == 3) {
+                        if ((v + 1) * 3 > palette.size()) return fail("palette index");
+                        d[0] = palette[v * 3]; d[1] = palette[v * 3 + 1]; d[2] = palette[v * 3 + 2];
+                        d[3] = v < trns.size() ? trns[v] : 255;
+                    } else {
+                        d[0] = d[1] = d[2] = (unsigned char)(v * 255u / maxVal);
+                        d[3] = (trns.size() >= 2 && v == ((unsigned)trns[0] << 8 | trns[1])) ? 0 : 255;
+                    }
+                    continue;
+                }
+                const size_t step = bitDepth / 8;  // 16-bit samples: keep the high byte
+                const unsigned char* sp = cur + x * bpp;
+                switch (colorType) {
+                    case 0:
+                        d[0] = d[1] = d[2] = sp[0];
+                        d[3] = 255;
+                        if (trns.size() >= 2 && (step == 2 ? (sp[0] == trns[0] && sp[1] == trns[1]) : (trns[0] == 0 && sp[0] == trns[1]))) d[3] = 0;
+                        break;
+                    case 2: {
+                        d[0] = sp[0]; d[1] = sp[step]; d[2] = sp[2 * step]; d[3] = 255;
+                        if (trns.size() >= 6) {
+                            bool key = true;
+                            for (int k = 0; k < 3 && key; ++k)
+                                key = step == 2 ? (sp[2 * k] == trns[2 * k] && sp[2 * k + 1] == trns[2 * k + 1])
+                                                : (trns[2 * k] == 0 && sp[k] == trns[2 * k + 1]);
+                            if (key) d[3] = 0;
+                        }
+                        break;
+                    }
+                    case 3: {
+                        const unsigned idx = sp[0];
+                        if ((idx + 1) * 3 > palette.size()) return fail("palette index");
+                        d[0] = palette[idx * 3]; d[1] = palette[idx * 3 + 1]; d[2] = palette[idx * 3 + 2];
+                        d[3] = idx < trns.size() ? trns[idx] : 255;
+                        break;
+                    }
+                    case 4: d[0] = d[1] = d[2] = sp[0]; d[3] = sp[step]; break;
+                    case 6: d[0] = sp[0]; d[1] = sp[step]; d[2] = sp[2 * step]; d[3] = sp[3 * step]; break;
+                }
             }
         }
     }

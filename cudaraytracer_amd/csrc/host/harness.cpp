@@ -389,6 +389,43 @@ int rth_read_png(const char* path, unsigned char* out, size_t outBytes, int* wid
     return 0;
 }
 
+// OBJ ingest probe: reads folder + file with ObjFileReader and returns the first model's geometry.
+// counts = {models, vertices, indices, materials}; verts (RtVertex layout) / inds may be NULL to query sizes;
+// texNames receives "diffuse\nnormal\nspecular" of the first material.
+int rth_obj_read(const char* folder, const char* file, int startAtZero, int* counts, RtVertex* verts, int vertCap, int* inds, int indCap,
+                 char* texNames, int texNamesLen) {
+    try {
+        const std::vector<model::Model> models = ObjFileReader().readFile(folder, file, startAtZero != 0);
+        counts[0] = (int)models.size();
+        counts[1] = counts[2] = counts[3] = 0;
+        if (models.empty()) return 0;
+        const model::Model& m = models[0];
+        counts[1] = (int)m.getVertices().size();
+        counts[2] = (int)m.getIndices().size();
+        counts[3] = (int)m.getMaterials().size();
+        if (verts) {
+            if (vertCap < counts[1]) return -2;
+            std::memcpy(verts, m.getVertices().data(), sizeof(Vertex) * m.getVertices().size());
+        }
+        if (inds) {
+            if (indCap < counts[2]) return -2;
+            std::memcpy(inds, m.getIndices().data(), sizeof(int) * m.getIndices().size());
+        }
+        if (texNames && texNamesLen > 0) {
+            std::string t;
+            if (!m.getMaterials().empty()) {
+                const model::Material& mt = m.getMaterials()[0];
+                t = mt.texturePath + "\n" + mt.normalMapPath + "\n" + mt.specularMapPath;
+            }
+            std::snprintf(texNames, (size_t)texNamesLen, "%s", t.c_str());
+        }
+        return 0;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return -1;
+    }
+}
+
 // Host BVH build over a triangle list, for parity checks against the oracle's builder.
 int rth_bvh_triangles(const RtVertex* verts, int vertCnt, const RtTriangle* tris, int triCnt, int threshold, int tight,
                       RtLinearNode* nodesOut, int* nodeCntOut, int* orderOut) {

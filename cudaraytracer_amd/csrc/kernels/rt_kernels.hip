@@ -603,6 +603,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
             unsigned v = vals[i];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
             if (lane == 0 && v && where[i] >= 0) atomicAdd(P.counters + where[i], (unsigned long long)v);
+            if (ANY && i < 4 && lane == 0 && v) atomicAdd(P.counters + RT_CNT_SHADOW_NODE + i, (unsigned long long)v);
         }
         if (lane == 0) {
             const int b = ANY ? RT_CNT_STAT_SHADOW : RT_CNT_STAT_CLOSEST;

@@ -1,0 +1,93 @@
+"""Multi-GPU frame rendering: one process per GPU, the scene blob broadcast once,
+every rank renders the 8x8 tiles t = rank, rank + world, ... of the SAME frame and
+the tiles are gathered to rank 0.
+
+The reference is single-GPU (cudaTracer/Main.cu:46-90 launches one grid over the
+whole surface); the tile of this module is the reference's thread block made
+8x8 pixels wide, and the interleaved assignment balances sky / geometry tiles
+across GPUs without a work queue between them.
+
+The only collectives are the one-off scene broadcast and the per-frame gather
+of finished tiles (point-to-point sends to rank 0: every peer has its own xGMI
+link to GPU 0, so the N-1 transfers run in parallel).  The functions work on
+any torch.distributed backend: "nccl" (RCCL) with device tensors in production,
+"gloo" with host tensors in the CPU tests.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+TILE = 8
+OPTS_BYTES = 48
+CAMERA_FLOATS = 3 + 16
+
+
+def tile_grid(width, height):
+    return (width + TILE - 1) // TILE, (height + TILE - 1) // TILE
+
+
+def tile_ids(width, height, rank, world):
+    tx, ty = tile_grid(width, height)
+    return torch.arange(rank, tx * ty, world)
+
+
+def tile_count(width, height, rank, world):
+    tx, ty = tile_grid(width, height)
+    return len(range(rank, tx * ty, world))
+
+
+def share_scene(blob, opts_bytes, camera_floats, rank, world, device):
+    """Rank 0 passes the packed scene blob (uint8 tensor on `device`), the 48 raw bytes of DeviceOpts and the
+    19 camera floats (origin + matrix); the other ranks pass None.  Returns (blob, opts_bytes, camera_floats) on every rank."""
+    head = torch.zeros(1, dtype=torch.int64, device=device)
+    small = torch.zeros(OPTS_BYTES + 4 * CAMERA_FLOATS, dtype=torch.uint8, device=device)
+    if rank == 0:
+        head[0] = blob.numel()
+        cam = np.asarray(camera_floats, dtype=np.float32)
+        assert len(opts_bytes) == OPTS_BYTES and cam.size == CAMERA_FLOATS
+        small.copy_(torch.frombuffer(bytearray(bytes(opts_bytes) + cam.tobytes()), dtype=torch.uint8))
+    if world > 1:
+        dist.broadcast(head, 0)
+        dist.broadcast(small, 0)
+    if rank != 0:
+        blob = torch.empty(int(head.item()), dtype=torch.uint8, device=device)
+    if world > 1:
+        dist.broadcast(blob, 0)
+    raw = small.cpu().numpy().tobytes()
+    return blob, raw[:OPTS_BYTES], np.frombuffer(raw[OPTS_BYTES:], dtype=np.float32).copy()
+
+
+class TileGather:
+    """Collects the tiles each rank rendered into the full frame on rank 0.  Frame sizes must be multiples of 8."""
+
+    def __init__(self, width, height, rank, world, device, channels=4, dtype=torch.float32):
+        if width % TILE or height % TILE:
+            raise ValueError("tile gather needs a frame size divisible by 8")
+        self.w, self.h, self.rank, self.world = width, height, rank, world
+        self.tx, self.ty = tile_grid(width, height)
+        self.c = channels
+        self.mine = tile_ids(width, height, rank, world).to(device)
+        self.recv = None
+        if rank == 0:
+            self.recv = [None] + [torch.empty((tile_count(width, height, r, world), TILE, TILE, channels), dtype=dtype, device=device)
+                                  for r in range(1, world)]
+            self.frame = torch.zeros((self.ty, self.tx, TILE, TILE, channels), dtype=dtype, device=device)
+
+    def tiles(self, surface):
+        """[h, w, c] surface -> [tiles, 8, 8, c] of this rank's tiles (a copy)."""
+        t = surface.view(self.ty, TILE, self.tx, TILE, self.c).permute(0, 2, 1, 3, 4).reshape(self.tx * self.ty, TILE, TILE, self.c)
+        return t.index_select(0, self.mine)
+
+    def gather(self, surface):
+        """Every rank passes its own surface (only its tiles are read).  Rank 0 returns the assembled [h, w, c] frame."""
+        mine = self.tiles(surface)
+        if self.rank != 0:
+            dist.send(mine, dst=0)
+            return None
+        reqs = [dist.irecv(self.recv[r], src=r) for r in range(1, self.world)]
+        flat = self.frame.view(self.tx * self.ty, TILE, TILE, self.c)
+        flat[0::self.world] = mine
+        for r, q in enumerate(reqs, start=1):
+            q.wait()
+            flat[r::self.world] = self.recv[r]
+        return self.frame.permute(0, 2, 1, 3, 4).reshape(self.h, self.w, self.c)

@@ -185,6 +185,11 @@ enum {
     RT_CNT_MESH_ENTRY = 6,/* ray -> object-space transforms                  */
     RT_CNT_SHADE_MESH = 7,/* shaded mesh hits                                */
     RT_CNT_SHADE_SPHERE = 8,
+    /* the share of NODE / TRI / SPHERE / MESH_ENTRY spent on shadow rays (four words, same order) */
+    RT_CNT_SHADOW_NODE = 9,
+    RT_CNT_SHADOW_TRI = 10,
+    RT_CNT_SHADOW_SPHERE = 11,
+    RT_CNT_SHADOW_MESH_ENTRY = 12,
     /* wave-step statistics of the trace kernels (diagnostics; six words each):
      * steps, node steps, lanes in node steps, triangle steps, lanes in triangle steps, lanes holding a ray */
     RT_CNT_STAT_CLOSEST = 16,
