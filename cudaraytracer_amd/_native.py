@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("RT_LIB") or os.path.join(_HERE, "librt_gfx950.so")
 RT_COUNTER_NAMES = ["primary", "shadow", "secondary", "node", "tri", "sphere", "mesh_entry", "shade_mesh", "shade_sphere"]
 RT_COUNTER_CNT = 32
 RT_MAX_DEPTH = 15
-RT_STACK_ENTRIES = 32
+RT_STACK_ENTRIES = 64
 
 
 class RtVertex(C.Structure):

@@ -21,4 +21,5 @@ pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_su
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
+python3 profiles/summarize_pmc.py "$OUT" > "$OUT/summary.txt" 2>&1; tail -60 "$OUT/summary.txt"
 echo done

@@ -1,24 +1,62 @@
 #!/usr/bin/env python3
-"""Prints per-kernel means of a profiles/run_pmc.sh output directory."""
+"""Prints per-kernel means of a profiles/run_pmc.sh / run_profile.sh output directory.
+
+  summarize_pmc.py <dir> [--traffic-json profiles/traffic.json --workload KEY]
+
+With --traffic-json the HBM bytes per launch of every kernel that has FETCH_SIZE and
+WRITE_SIZE samples are merged into that file:
+  hbm = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024
+(both counters are in KB; on gfx950 FETCH_SIZE tallies 128-byte fabric reads at 64 bytes, so it is
+doubled; for this kernel's divergent 64-byte line reads the factor is uncalibrated, which makes the
+figure an upper bound).
+"""
+import argparse
 import collections
 import csv
 import glob
-import sys
+import json
+import os
+import re
 
-out = sys.argv[1]
+ap = argparse.ArgumentParser()
+ap.add_argument("out")
+ap.add_argument("--traffic-json")
+ap.add_argument("--workload", default="default")
+args = ap.parse_args()
+out = args.out
+
+
+def short(name):
+    m = re.search(r"(\w+Kernel(?:<[^>]*>)?)", name)
+    return m.group(1) if m else name[:60]
+
+
 for f in glob.glob(f"{out}/trace/**/*_kernel_stats.csv", recursive=True):
-    print("# kernel stats (ns)")
+    print("# kernel stats")
     for r in csv.DictReader(open(f)):
-        if float(r["Percentage"]) > 0.5:
-            print(f'{r["Name"][:70]:70s} calls {r["Calls"]:>4s} avg {float(r["AverageNs"])/1e3:10.1f} us  {r["Percentage"]}%')
+        if float(r["Percentage"]) > 0.2:
+            print(f'{short(r["Name"]):40s} calls {r["Calls"]:>5s} avg {float(r["AverageNs"])/1e3:10.1f} us  {r["Percentage"]}%')
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{out}/*/**/*_counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "Kernel" not in k or "at::" in k:
             continue
-        agg[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, d in agg.items():
+        agg[short(k)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+traffic = {}
+for k, d in sorted(agg.items()):
     print("#", k)
     for c, v in sorted(d.items()):
         print(f"   {c:32s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
+    if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+        fetch = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]) * 1024
+        write = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"]) * 1024
+        traffic[k] = {"fetch_size_bytes_raw": fetch, "write_size_bytes": write, "hbm_bytes_per_launch": 2 * fetch + write}
+        print(f"   => HBM bytes per launch: 2 x {fetch/1e6:.1f} MB + {write/1e6:.1f} MB = {(2*fetch+write)/1e6:.1f} MB")
+if args.traffic_json and traffic:
+    table = {}
+    if os.path.exists(args.traffic_json):
+        table = json.load(open(args.traffic_json))
+    table[args.workload] = traffic
+    json.dump(table, open(args.traffic_json, "w"), indent=1, sort_keys=True)
+    print("wrote", args.traffic_json)

@@ -35,3 +35,209 @@ def test_frame_matches_oracle(gpu_ctx, oracle, name, w, h, size, lights, depth, 
     rgba2, keys2, _ = gpu_ctx.render_frame(scene, want_keys=True)
     assert np.array_equal(keys, keys2)
     assert np.array_equal(rgba, rgba2, equal_nan=True)
+
+
+# ---- golden frames (no oracle run involved) -------------------------------------------------
+import os  # noqa: E402
+import sys  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLDEN)
+import make_golden  # noqa: E402
+
+
+@pytest.mark.parametrize("key", sorted(make_golden.FRAMES))
+def test_frame_matches_golden(gpu_ctx, key):
+    name, w, h, size, lights, depth, tight = make_golden.FRAMES[key]
+    g = np.load(os.path.join(GOLDEN, f"frame_{key}.npz"))
+    scene = rt.HostScene(name, w, h, size, lights, depth, tight_bvh=tight)
+    rgba, keys, cnt = gpu_ctx.render_frame(scene, want_keys=True, want_counters=True)
+    assert_parity(rgba, keys, g["rgba"], g["keys"])
+    assert [cnt[n] for n in rt.RT_COUNTER_NAMES] == g["counters"].tolist()
+
+
+# ---- the reference's option switches ---------------------------------------------------------
+@pytest.mark.parametrize("scene_bvh,mesh_bvh", [(0, 1), (1, 0), (0, 0)])
+def test_linear_scan_modes(gpu_ctx, oracle, scene_bvh, mesh_bvh):
+    """Options.cuh:23-24 useSceneBvh / useMeshBvhs off: linear scans over shapes / triangles."""
+    w, h = 96, 64
+    scene = rt.HostScene("mixed", w, h, 0, 3, 3, tight_bvh=True)
+    scene.opts.contents.useSceneBvh = scene_bvh
+    scene.opts.contents.useMeshBvhs = mesh_bvh
+    ref_rgba, ref_keys, ref_cnt = oracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=8, shadow_any_hit=True)
+    rgba, keys, cnt = gpu_ctx.render_frame(scene, want_keys=True, want_counters=True)
+    assert_parity(rgba, keys, ref_rgba, ref_keys)
+    assert cnt == ref_cnt, (cnt, ref_cnt)
+
+
+def test_gamma_and_background_options(gpu_ctx, oracle):
+    w, h = 96, 64
+    scene = rt.HostScene("mixed", w, h, 0, 2, 2)
+    scene.opts.contents.gammaCorrection = 0
+    scene.opts.contents.backgroundColor[:] = [0.9, 0.1, 0.3]
+    scene.opts.contents.shadowBias = 1e-2
+    ref_rgba, ref_keys, _ = oracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=8, shadow_any_hit=True)
+    rgba, keys, _ = gpu_ctx.render_frame(scene, want_keys=True)
+    assert_parity(rgba, keys, ref_rgba, ref_keys)
+    assert np.array_equal(rgba[keys[..., 0] < 0][:, :3], np.broadcast_to(np.float32([0.9, 0.1, 0.3]), (int((keys[..., 0] < 0).sum()), 3)))
+
+
+# ---- kernel knobs must not change a single bit -----------------------------------------------
+def test_knobs_do_not_change_the_frame(gpu_ctx):
+    scene = rt.HostScene("soup", 192, 108, 100000, 2, 0, tight_bvh=True)
+    dscene = gpu_ctx.upload(scene)
+    try:
+        base = gpu_ctx.render_frame(scene, dscene, want_keys=True, want_counters=True)
+        for setter, values, restore in ((gpu_ctx.set_lds_stack, (1, 3, 8, 64), 20), (gpu_ctx.set_subframes, (2, 5, 8), 1),
+                                        (gpu_ctx.set_trace_waves, (1, 4, 32), 0)):
+            try:
+                for v in values:
+                    setter(v)
+                    got = gpu_ctx.render_frame(scene, dscene, want_keys=True, want_counters=True)
+                    assert np.array_equal(got[1], base[1]), (setter.__name__, v)
+                    assert np.array_equal(got[0], base[0], equal_nan=True), (setter.__name__, v)
+                    assert got[2] == base[2], (setter.__name__, v)
+            finally:
+                setter(restore)
+    finally:
+        gpu_ctx.free_scene(dscene)
+
+
+def test_deep_stack_spills_to_global_memory(gpu_ctx, oracle):
+    """A 1-entry LDS stack forces nearly every push through the spill buffer, with secondary rays in flight."""
+    w, h = 96, 64
+    scene = rt.HostScene("mixed", w, h, 0, 3, 4)
+    ref_rgba, ref_keys, ref_cnt = oracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=8, shadow_any_hit=True)
+    gpu_ctx.set_lds_stack(1)
+    try:
+        rgba, keys, cnt = gpu_ctx.render_frame(scene, want_keys=True, want_counters=True)
+    finally:
+        gpu_ctx.set_lds_stack(20)
+    assert_parity(rgba, keys, ref_rgba, ref_keys)
+    assert cnt == ref_cnt
+
+
+# ---- tile shards, scene hand-over, lights ------------------------------------------------------
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_tile_shards_compose_the_frame(gpu_ctx, world):
+    w, h = 200, 120
+    scene = rt.HostScene("mixed", w, h, 0, 3, 3)
+    dscene = gpu_ctx.upload(scene)
+    surf, pitch = gpu_ctx.surface(w, h)
+    keys = gpu_ctx.alloc(w * h * 16)
+    cnt = gpu_ctx.alloc(rt.RT_COUNTER_CNT * 8)
+    try:
+        full = gpu_ctx.render_frame(scene, dscene, want_keys=True, want_counters=True)
+        gpu_ctx.zero(surf, pitch * h)
+        gpu_ctx.zero(keys, w * h * 16)
+        gpu_ctx.zero(cnt, rt.RT_COUNTER_CNT * 8)
+        for r in range(world):
+            gpu_ctx.render(dscene, scene.opts, scene.camera, surf, pitch, keys, cnt, r, world)
+        gpu_ctx.sync()
+        rgba = gpu_ctx.download_surface(surf, pitch, w, h)
+        k = gpu_ctx.download(keys, (h, w, 4), np.int32)
+        c = gpu_ctx.download(cnt, (rt.RT_COUNTER_CNT,), np.uint64)
+        assert np.array_equal(k, full[1])
+        assert np.array_equal(rgba, full[0], equal_nan=True)
+        assert {n: int(c[i]) for i, n in enumerate(rt.RT_COUNTER_NAMES)} == full[2]  # counters add up over shards
+    finally:
+        gpu_ctx.free(surf)
+        gpu_ctx.free(keys)
+        gpu_ctx.free(cnt)
+        gpu_ctx.free_scene(dscene)
+
+
+def test_adopted_blob_renders_like_an_uploaded_scene(gpu_ctx):
+    import torch
+
+    w, h = 128, 80
+    scene = rt.HostScene("mixed", w, h, 0, 2, 3)
+    base = gpu_ctx.render_frame(scene, want_keys=True)
+    blob = torch.from_numpy(gpu_ctx.pack(scene.desc)).to("cuda:0")
+    torch.cuda.synchronize()
+    dscene = gpu_ctx.adopt_blob(blob.data_ptr(), blob.numel())
+    try:
+        got = gpu_ctx.render_frame(scene, dscene, want_keys=True)
+        assert np.array_equal(got[1], base[1]) and np.array_equal(got[0], base[0], equal_nan=True)
+        # and the blob read back from an uploaded scene is the packed blob
+        up = gpu_ctx.upload(scene)
+        ptr, n = gpu_ctx.scene_blob(up)
+        assert n == blob.numel()
+        assert np.array_equal(gpu_ctx.download(ptr, (n,), np.uint8), blob.cpu().numpy())
+        gpu_ctx.free_scene(up)
+    finally:
+        gpu_ctx.free_scene(dscene)
+    with pytest.raises(rt.RtError):
+        gpu_ctx.adopt_blob(blob.data_ptr() + 256, blob.numel() - 256)  # not a blob header
+
+
+def test_moving_lights_without_a_new_upload(gpu_ctx, oracle):
+    """RayTracer.cpp:199-205 rotates the lights every frame and re-uploads only the light table."""
+    w, h = 96, 64
+    scene = rt.HostScene("mixed", w, h, 0, 3, 2)
+    dscene = gpu_ctx.upload(scene)
+    try:
+        for _ in range(2):
+            scene.rotate_lights(0.7)
+            gpu_ctx.set_lights(dscene, scene.desc)
+            ref_rgba, ref_keys, _ = oracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=8, shadow_any_hit=True)
+            rgba, keys, _ = gpu_ctx.render_frame(scene, dscene, want_keys=True)
+            assert_parity(rgba, keys, ref_rgba, ref_keys)
+    finally:
+        gpu_ctx.free_scene(dscene)
+
+
+def test_path_budget_overflow_is_reported(gpu_ctx):
+    """Glass spawns two children per hit; with one node per pixel the arrays overflow and rt_sync says so."""
+    scene = rt.HostScene("mixed", 128, 96, 0, 2, 6)
+    gpu_ctx.set_path_budget(1)
+    try:
+        with pytest.raises(rt.RtError, match="budget|overflow|path"):
+            gpu_ctx.render_frame(scene)
+    finally:
+        gpu_ctx.set_path_budget(3)
+    gpu_ctx.render_frame(scene)  # the context stays usable
+
+
+def test_bad_render_arguments(gpu_ctx):
+    scene = rt.HostScene("cubes", 64, 48, 3, 1, 0)
+    dscene = gpu_ctx.upload(scene)
+    surf, pitch = gpu_ctx.surface(64, 48)
+    try:
+        with pytest.raises(rt.RtError):
+            gpu_ctx.render(dscene, scene.opts, scene.camera, surf, 64 * 16 - 4)  # pitch too small
+        with pytest.raises(rt.RtError):
+            gpu_ctx.render(dscene, scene.opts, scene.camera, surf, pitch, None, None, 3, 2)  # tileFirst >= tileStride
+        scene.opts.contents.maxDepth = 99
+        with pytest.raises(rt.RtError):
+            gpu_ctx.render(dscene, scene.opts, scene.camera, surf, pitch)
+        scene.opts.contents.maxDepth = 0
+        scene.opts.contents.samples = 4
+        with pytest.raises(rt.RtError):
+            gpu_ctx.render(dscene, scene.opts, scene.camera, surf, pitch)
+    finally:
+        gpu_ctx.free(surf)
+        gpu_ctx.free_scene(dscene)
+
+
+# ---- the headline workload at full size ------------------------------------------------------
+def test_full_size_soup_properties(gpu_ctx, oracle):
+    """1080p over the 1M-triangle soup: sampled rows against the oracle, and size-independent properties
+    (determinism, shard composition, ray-count identities)."""
+    w, h = 1920, 1080
+    scene = rt.HostScene("soup", w, h, 1000000, 1, 0, tight_bvh=True)
+    dscene = gpu_ctx.upload(scene)
+    try:
+        rgba, keys, cnt = gpu_ctx.render_frame(scene, dscene, want_keys=True, want_counters=True)
+        rows = (3, h, 45)
+        ref_rgba, ref_keys, _ = oracle.render(scene.desc, scene.opts, scene.camera, w, h, rows=rows, threads=16, shadow_any_hit=True)
+        sel = slice(*rows)
+        assert_parity(rgba[sel], keys[sel], ref_rgba[sel], ref_keys[sel])
+        hit = keys[..., 0] >= 0
+        assert cnt["primary"] == w * h
+        assert cnt["shade_mesh"] == int(hit.sum()) and cnt["shadow"] == int(hit.sum()) * 1
+        assert 0.3 < hit.mean() < 0.9
+        again = gpu_ctx.render_frame(scene, dscene, want_keys=True)
+        assert np.array_equal(again[1], keys) and np.array_equal(again[0], rgba, equal_nan=True)
+    finally:
+        gpu_ctx.free_scene(dscene)
