@@ -24,6 +24,8 @@
 // Only powf (gamma, Blinn-Phong) may differ in the last ulp.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "../rt_device_format.h"
 
@@ -37,11 +39,8 @@ constexpr unsigned kChunk = RT_CHUNK;  // rays a wavefront takes from the global
 #ifndef RT_REFILL_LANES
 #define RT_REFILL_LANES 8  // a wavefront refills once this many lanes have finished their rays
 #endif
-#ifndef RT_TRI_BATCH
-#define RT_TRI_BATCH 4  // triangle records fetched and tested per step (the packer pads the record array accordingly)
-#endif
 #ifndef RT_TRI_LANES
-#define RT_TRI_LANES 20  // triangle steps start once this many lanes wait in a leaf
+#define RT_TRI_LANES 20  // a triangle phase starts once this many lanes wait in a leaf
 #endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1  // __launch_bounds__ waves per SIMD for the trace kernel
@@ -115,30 +114,6 @@ __device__ __forceinline__ bool boxSlabs(const float4 n0, const float4 n1, const
     if (tzMax < tMax) tMax = tzMax;
     tMinOut = tMin;
     return ok && (tMax > 0);
-}
-
-// cudaTracer/Mesh.cuh:182-212 on a precomputed {v0, e1, e2} record.
-__device__ __forceinline__ bool triangleHit(const float4 r0, const float4 r1, const float e2z, const V3 o, const V3 d,
-                                            float& tMax, float& uOut, float& vOut) {
-    const V3 v0 = mk(r0.x, r0.y, r0.z);
-    const V3 e1 = mk(r0.w, r1.x, r1.y);
-    const V3 e2 = mk(r1.z, r1.w, e2z);
-    const V3 pvec = cross(d, e2);
-    const float det = dot(e1, pvec);
-    if (det == 0.0f || det < 0.0f) return false;
-    const V3 tvec = sub(o, v0);
-    const float u = dot(tvec, pvec);
-    if (u < 0.0f || u > det) return false;
-    const V3 qvec = cross(tvec, e1);
-    const float v = dot(d, qvec);
-    if (v < 0.0f || u + v > det) return false;
-    const float invDet = 1.0f / det;
-    const float t = dot(e2, qvec) * invDet;
-    if (t < 0.0f || tMax < t) return false;
-    tMax = t;
-    uOut = u * invDet;
-    vOut = v * invDet;
-    return true;
 }
 
 // cudaTracer/Sphere.cuh:9-54
@@ -232,7 +207,47 @@ __device__ __forceinline__ void shadowRay(const FrameParams& P, unsigned k, int 
     o = biasedOrigin(view, hitPoint, n, P.opts.shadowBias);
 }
 
-enum { MODE_NODE = 0, MODE_TRI = 1, MODE_SHAPE = 2, MODE_POP = 3, MODE_DONE = 4 };
+// What a lane does next is held in ONE word, `cur`:
+//   bit 31 clear          an interior node reference: expand it (fetch its child pair)
+//   10 | next (30 bits)   inside a mesh-BVH leaf: triangle records next .. end-1 are to be tested
+//   11 | next (30 bits)   inside a scene-BVH leaf: shapes next .. end-1 are to be tested
+//   CUR_POP               take the next entry from the traversal stack
+//   CUR_DONE              the ray is finished (also the value of a lane without a ray)
+constexpr unsigned CUR_POP = 0xFFFFFFFFu, CUR_DONE = 0xFFFFFFFEu;
+constexpr unsigned TAG_TRI = 0x80000000u, TAG_SHAPE = 0xC0000000u, IDX_MASK = 0x3FFFFFFFu;
+constexpr unsigned STACK_MESH_EXIT = 0xFFFFFFFDu;  // stack marker: the mesh walk is over, restore the world-space ray
+constexpr int HIT_PENDING = -3;                    // hShape while the hit mesh is still being walked
+
+#ifndef RT_TRI_PART
+#define RT_TRI_PART 32  // rays whose leaves are tested in one cooperative triangle phase (8 lanes each, 8 rays per round)
+#endif
+constexpr int kTriPart = RT_TRI_PART;
+constexpr size_t kTriLdsBytes = (size_t)kTriPart * (2 * sizeof(float4) + 8 * sizeof(float) + 8 * sizeof(float2));
+
+__host__ __device__ constexpr size_t traceLdsBytes(int stackLds) { return (size_t)(stackLds + 1) * kWave * sizeof(uint2) + kTriLdsBytes; }
+
+// cudaTracer/Mesh.cuh:182-212 on a precomputed {v0, e1, e2} record, WITHOUT the final comparison
+// against the ray's reach: returns false if one of the determinant / barycentric tests rejects the
+// triangle, else t, u, v exactly as the reference forms them.
+__device__ __forceinline__ bool triangleSolve(const float4 r0, const float4 r1, const float e2z, const V3 o, const V3 d,
+                                              float& tOut, float& uOut, float& vOut) {
+    const V3 v0 = mk(r0.x, r0.y, r0.z);
+    const V3 e1 = mk(r0.w, r1.x, r1.y);
+    const V3 e2 = mk(r1.z, r1.w, e2z);
+    const V3 pvec = cross(d, e2);
+    const float det = dot(e1, pvec);
+    const V3 tvec = sub(o, v0);
+    const float u = dot(tvec, pvec);
+    const V3 qvec = cross(tvec, e1);
+    const float v = dot(d, qvec);
+    const bool reject = (det == 0.0f || det < 0.0f) || (u < 0.0f || u > det) || (v < 0.0f || u + v > det);
+    if (reject) return false;
+    const float invDet = 1.0f / det;
+    tOut = dot(e2, qvec) * invDet;
+    uOut = u * invDet;
+    vOut = v * invDet;
+    return true;
+}
 
 // ---------------------------------------------------------------------------
 // Persistent traversal kernel.  ANY = false: closest hit for the path nodes of
@@ -241,21 +256,34 @@ enum { MODE_NODE = 0, MODE_TRI = 1, MODE_SHAPE = 2, MODE_POP = 3, MODE_DONE = 4 
 // accepted primitive, which yields the same boolean as the reference's full
 // walk because acceptance of that primitive does not depend on later tests.
 //
-// Every LANE owns one ray and runs a small state machine:
-//   NODE   expand an interior node: ONE 64-byte fetch brings both child boxes;
-//          the near child (by the sign of the ray along the split axis) is
-//          tested against the ray's current reach and entered, the far child is
-//          pushed together with its entry distance
-//   POP    take the next far child; it is entered iff its stored entry distance
-//          is still below the ray's reach - the same decision the reference
-//          makes when it tests that box at pop time, since the reach is the
-//          only input of the box test that changes along the walk
-//   TRI    test the triangles of a leaf, two records per step
-//   SHAPE  a scene-BVH leaf: sphere test, or change to the mesh's object space
+// Every LANE owns one ray.  Per iteration the wavefront votes for ONE kind of
+// work, so that each (long) block of code runs with as many lanes as possible:
+//
+//   node step       every lane that sits on an interior node expands it: ONE
+//                   64-byte fetch brings both child boxes; the near child (by the
+//                   sign of the ray along the split axis) is tested against the
+//                   ray's current reach and entered, the far child is pushed
+//                   together with its entry distance
+//   triangle phase  the lanes that sit in a mesh leaf (up to RT_TRI_PART of
+//                   them) publish their rays in LDS and ALL 64 lanes test the
+//                   leaves' triangles, 8 lanes per ray, one triangle per lane
+//                   (coalesced 48-byte record reads); the results go back through
+//                   LDS and each owner applies them IN LEAF ORDER with the
+//                   reference's rule (a hit at t <= reach replaces the current
+//                   one, so of equal distances the later triangle wins)
+//
+// followed by the rare per-lane work: scene-leaf shapes (sphere test, or the
+// change to a mesh's object space) and stack pops.  A popped entry is entered
+// iff its stored entry distance is still below the ray's reach - the same
+// decision the reference makes when it tests that box at pop time, since the
+// reach is the only input of the box test that changes along the walk.
+//
 // The stack (8 bytes per entry: node reference + entry distance) lives in LDS,
-// one column per lane, shared by the scene BVH and the mesh BVH.  Visiting
-// order, near/far choice and the <=-tie rule are the reference's, so results do
-// not depend on which lane or wavefront a ray lands in.
+// one column per lane, with a global-memory continuation for deep entries; it
+// is shared by the scene BVH and the mesh BVH.  While a mesh is walked it also
+// keeps the world-space ray (RT_MESH_ENTRY_SLOTS entries under a marker).
+// Visiting order, near/far choice and the <=-tie rule are the reference's, so
+// results do not depend on which lane or wavefront a ray lands in.
 //
 // Counting (COUNT): a box test is tallied when the reference would perform it -
 // the near child at once, a far child when popped - so the totals equal the
@@ -264,18 +292,22 @@ enum { MODE_NODE = 0, MODE_TRI = 1, MODE_SHAPE = 2, MODE_POP = 3, MODE_DONE = 4 
 // infinite entry distance).
 template <bool ANY, bool COUNT>
 __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FrameParams P, const int level) {
-    extern __shared__ uint2 s_stack[];
+    extern __shared__ uint2 s_dyn[];
     const int lane = threadIdx.x;
-    uint2* const stk = s_stack + lane;
-    // entries beyond the LDS part of the stack live in this wavefront's slice of a global array
     const int ldsEntries = P.stackLds;
+    uint2* const stk = s_dyn + lane;  // entry e of this lane: stk[e * 64]; entry ldsEntries is a write-only dump slot
+    float4* const rayBuf = reinterpret_cast<float4*>(s_dyn + (size_t)(ldsEntries + 1) * kWave);  // [kTriPart][2]
+    float* const tBuf = reinterpret_cast<float*>(rayBuf + 2 * kTriPart);                         // [kTriPart][8]
+    float2* const uvBuf = reinterpret_cast<float2*>(tBuf + 8 * kTriPart);                        // [kTriPart][8]
+    // entries beyond the LDS part of the stack live in this wavefront's slice of a global array
     uint2* const gstk = P.stackSpill + ((size_t)blockIdx.x * (size_t)(P.stackEntries - P.stackLds)) * kWave + lane;
 
     const unsigned total = ANY ? P.ctl[CTL_DIFFUSE_CNT] * (unsigned)P.lightCnt : P.ctl[CTL_LEVEL_COUNT + level];
     const unsigned first = ANY ? 0u : P.ctl[CTL_LEVEL_START + level];
     unsigned* const queue = P.ctl + (ANY ? CTL_SHADOW_QUEUE : CTL_TRACE_QUEUE);
 
-    const float4* const sceneNodes = reinterpret_cast<const float4*>(P.blob + P.offSceneNodes);
+    const float4* const blob4 = reinterpret_cast<const float4*>(P.blob);
+    const float4* const records = reinterpret_cast<const float4*>(P.blob + P.offRecords);
     const DevShape* const shapes = reinterpret_cast<const DevShape*>(P.blob + P.offShapes);
     const DevMesh* const meshes = reinterpret_cast<const DevMesh*>(P.blob + P.offMeshes);
     const bool useSceneBvh = P.opts.useSceneBvh != 0;
@@ -283,7 +315,8 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     const float kInf = __builtin_huge_valf();
 
     unsigned cNode = 0, cTri = 0, cSphere = 0, cMesh = 0, cRays = 0, cPrimary = 0;
-    // wave-level step statistics (lane 0 only): steps, lanes expanding nodes, lanes testing triangles, lanes with a ray
+    // wave-level statistics (meaningful in lane 0): iterations, node steps and their lanes, triangle phases and their
+    // rays, lanes holding a ray
     unsigned long long wSteps = 0, wNodeLanes = 0, wTriLanes = 0, wBusyLanes = 0, wNodeSteps = 0, wTriSteps = 0;
 
     // wave-uniform queue state
@@ -291,56 +324,35 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     bool exhausted = false;
 
     // per-lane ray state
-    int item = -1;  // work item (node index or shadow index); -1 = idle
-    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), inv = mk(0, 0, 0), wo = o, wd = d;
-    bool nx = false, ny = false, nz = false;
+    int item = -1;  // work item (node index or shadow index); -1 = no ray
+    V3 o = mk(0, 0, 0), d = mk(0, 0, 1), inv = mk(0, 0, 0);
     float tMax = 0.0f;
-    int mode = MODE_DONE;
-    unsigned ref = 0;  // interior node to expand (MODE_NODE)
-    int sp = 0, base = 0;
-    int shapeNext = 0, shapeEnd = 0, curShape = -1;
-    int triNext = 0, triEnd = 0;
-    bool inBlas = false, blasHit = false, hitAny = false;
+    unsigned cur = CUR_DONE, end = 0;
+    int sp = 0;
     int hShape = -1, hTri = -1;
     float hu = 0.0f, hv = 0.0f;
-    const float4* nodes = sceneNodes;
-    const float4* tris = nullptr;
 
+    auto push = [&](unsigned x, unsigned y) {
+        if (sp < ldsEntries)
+            stk[sp * kWave] = make_uint2(x, y);
+        else
+            gstk[(size_t)(sp - ldsEntries) * kWave] = make_uint2(x, y);
+        ++sp;
+    };
+    auto pop = [&]() -> uint2 {
+        --sp;
+        return sp < ldsEntries ? stk[sp * kWave] : gstk[(size_t)(sp - ldsEntries) * kWave];
+    };
     // enter the node described by reference r (its box test has passed)
-#define RT_ENTER(r)                                   \
-    do {                                              \
-        const unsigned r_ = (r);                      \
-        if (RT_REF_IS_LEAF(r_)) {                     \
-            const int f_ = (int)RT_REF_LEAF_FIRST(r_); \
-            const int c_ = (int)RT_REF_LEAF_COUNT(r_); \
-            if (inBlas) {                             \
-                triNext = f_;                         \
-                triEnd = f_ + c_;                     \
-                mode = MODE_TRI;                      \
-            } else {                                  \
-                shapeNext = f_;                       \
-                shapeEnd = f_ + c_;                   \
-                mode = MODE_SHAPE;                    \
-            }                                         \
-        } else {                                      \
-            ref = r_;                                 \
-            mode = MODE_NODE;                         \
-        }                                             \
-    } while (0)
-    // test the root record of the current tree (cudaTracer/Scene.cuh:38-39, cudaTracer/Mesh.cuh:137-138)
-#define RT_ROOT()                                                         \
-    do {                                                                  \
-        const float4 a_ = nodes[0], b_ = nodes[1];                        \
-        float t_;                                                         \
-        if (COUNT) cNode++;                                               \
-        if (boxSlabs(a_, b_, o, inv, nx, ny, nz, t_) && t_ < tMax)        \
-            RT_ENTER(__float_as_uint(b_.z));                              \
-        else                                                              \
-            mode = MODE_POP;                                              \
-    } while (0)
+    auto enter = [&](unsigned r) {
+        const unsigned f = RT_REF_LEAF_FIRST(r);
+        const bool leaf = RT_REF_IS_LEAF(r);
+        cur = leaf ? ((r & RT_REF_TAG_MASK) | f) : r;
+        end = f + RT_REF_LEAF_COUNT(r);
+    };
 
     while (true) {
-        // ---- hand new rays to idle lanes ---------------------------------
+        // ---- hand new rays to lanes without one ----------------------------
         const unsigned long long idle = __ballot(item < 0);
         if (idle != 0ull && !exhausted) {
             const unsigned want = (unsigned)__popcll(idle);
@@ -363,7 +375,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                 chunkNext += take;
                 given += take;
             }
-            if (item >= 0 && mode == MODE_DONE) {
+            if (item >= 0 && cur == CUR_DONE) {
                 // ---- start this lane's new ray
                 bool valid = true;
                 if (ANY) {
@@ -384,25 +396,13 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                 if (valid) {
                     if (COUNT) cRays++;
                     inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                    nx = inv.x < 0;
-                    ny = inv.y < 0;
-                    nz = inv.z < 0;
-                    nodes = sceneNodes;
-                    inBlas = false;
-                    blasHit = false;
-                    hitAny = false;
                     hShape = -1;
                     hTri = -1;
                     hu = hv = 0.0f;
                     sp = 0;
-                    base = 0;
-                    if (useSceneBvh) {
-                        RT_ROOT();
-                    } else {
-                        shapeNext = 0;
-                        shapeEnd = P.shapeCnt;
-                        mode = MODE_SHAPE;
-                    }
+                    // cudaTracer/Scene.cuh:38-39: the walk starts with the root's box test
+                    cur = useSceneBvh ? P.sceneRootRef : TAG_SHAPE;
+                    end = (unsigned)P.shapeCnt;
                 } else {
                     // tile pixel outside the frame: no ray, marked so that later stages skip it
                     P.hit[item] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(-2));
@@ -415,105 +415,125 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
             continue;
         }
 
-        // ---- advance every active lane until enough lanes have finished -----
+        // ---- advance the rays until enough lanes have finished --------------
         while (true) {
-            // One kind of step per iteration for the whole wavefront: either every lane that sits
-            // on an interior node expands it, or every lane that sits in a leaf tests triangles.
-            // Lanes of the other kind wait, so each (long) block runs with many lanes instead of
-            // both blocks running half empty.  Triangle steps are taken once enough lanes have
-            // reached a leaf, or when nobody has a node to expand.
-            const unsigned long long nodeLanes = __ballot(mode == MODE_NODE);
-            const unsigned long long triLanes = __ballot(mode == MODE_TRI);
-            const bool triStep = triLanes != 0ull && (__popcll(triLanes) >= RT_TRI_LANES || nodeLanes == 0ull);
-            const bool isNode = !triStep && mode == MODE_NODE, isTri = triStep && mode == MODE_TRI;
+            const unsigned long long nodeMask = __ballot((int)cur >= 0);
+            const unsigned long long triMask = __ballot((cur >> 30) == 2u);
+            const int nTri = __popcll(triMask);
+            const bool triPhase = nTri != 0 && (nTri >= RT_TRI_LANES || nodeMask == 0ull);
             if (COUNT) {
                 wSteps++;
-                wBusyLanes += __popcll(__ballot(item >= 0 && mode != MODE_DONE));
-                if (triStep) {
+                wBusyLanes += __popcll(__ballot(cur != CUR_DONE));
+            }
+            if (triPhase) {
+                // ================= cooperative triangle phase =================
+                const bool isTri = (cur >> 30) == 2u;
+                const unsigned rank = laneRank(triMask);
+                const bool part = isTri && rank < (unsigned)kTriPart;
+                const unsigned next = cur & IDX_MASK;
+                const int nPart = nTri < kTriPart ? nTri : kTriPart;
+                if (COUNT) {
                     wTriSteps++;
-                    wTriLanes += __popcll(triLanes);
-                } else if (nodeLanes != 0ull) {
-                    wNodeSteps++;
-                    wNodeLanes += __popcll(nodeLanes);
+                    wTriLanes += nPart;
                 }
-            }
-            float4 L0, L1, L2, L3;
-            float4 TA[RT_TRI_BATCH], TB[RT_TRI_BATCH];
-            float TC[RT_TRI_BATCH];
-            L0 = L1 = L2 = L3 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (isNode) {
-                const float4* p = nodes + 2 * (size_t)RT_REF_PAIR(ref);
-                L0 = p[0];
-                L1 = p[1];
-                L2 = p[2];
-                L3 = p[3];
-            }
-            if (isTri) {
-                const float4* p = tris + 3 * (size_t)triNext;
-#pragma unroll
-                for (int k = 0; k < RT_TRI_BATCH; ++k) {
-                    TA[k] = p[3 * k];
-                    TB[k] = p[3 * k + 1];
-                    TC[k] = reinterpret_cast<const float*>(p + 3 * k + 2)[0];
+                if (part) {
+                    rayBuf[2 * rank] = make_float4(o.x, o.y, o.z, __uint_as_float(next));
+                    rayBuf[2 * rank + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(end));
                 }
-            }
-            if (isNode) {
-                float t0, t1;
-                const bool g0 = boxSlabs(L0, L1, o, inv, nx, ny, nz, t0);
-                const bool g1 = boxSlabs(L2, L3, o, inv, nx, ny, nz, t1);
-                const unsigned axis = RT_REF_AXIS(ref);
-                const bool negAxis = axis == 0 ? nx : (axis == 1 ? ny : nz);
-                // cudaTracer/Mesh.cuh:155-161: with a negative direction along the split axis the
-                // second child is nearer; the other one waits on the stack
-                const unsigned nearRef = __float_as_uint(negAxis ? L3.z : L1.z);
-                const unsigned farRef = __float_as_uint(negAxis ? L1.z : L3.z);
-                const bool nearGeo = negAxis ? g1 : g0, farGeo = negAxis ? g0 : g1;
-                const float nearT = negAxis ? t1 : t0, farT = negAxis ? t0 : t1;
-                const bool farHit = farGeo && farT < tMax;
-                if (COUNT || farHit) {
-                    const uint2 e = make_uint2(farRef, __float_as_uint(farHit ? farT : kInf));
-                    if (sp < ldsEntries)
-                        stk[sp * kWave] = e;
-                    else
-                        gstk[(size_t)(sp - ldsEntries) * kWave] = e;
-                    ++sp;
-                }
-                if (COUNT) cNode++;
-                if (nearGeo && nearT < tMax)
-                    RT_ENTER(nearRef);
-                else
-                    mode = MODE_POP;
-            }
-            if (isTri) {
-                // cudaTracer/Mesh.cuh:141-146: leaf triangles in order; a later hit at equal t replaces an earlier one
-#pragma unroll
-                for (int k = 0; k < RT_TRI_BATCH; ++k) {
-                    if (!(ANY && hitAny) && triNext + k < triEnd) {
-                        if (COUNT) cTri++;
-                        if (triangleHit(TA[k], TB[k], TC[k], o, d, tMax, hu, hv)) {
-                            hTri = triNext + k;
-                            blasHit = true;
-                            if (ANY) hitAny = true;
+                __syncthreads();
+                const int rounds = (nPart + 7) >> 3;
+                for (int r = 0; r < rounds; ++r) {
+                    const int rr = r * 8 + (lane >> 3);
+                    const unsigned k = (unsigned)lane & 7u;
+                    const float4 A = rayBuf[2 * rr], B = rayBuf[2 * rr + 1];
+                    const unsigned idx = __float_as_uint(A.w) + k;
+                    float t = -1.0f, u = 0.0f, v = 0.0f;
+                    if (rr < nPart && idx < __float_as_uint(B.w)) {
+                        const float4* rec = records + 3 * (size_t)idx;
+                        const float4 r0 = rec[0], r1 = rec[1];
+                        const float e2z = reinterpret_cast<const float*>(rec + 2)[0];
+                        float tt, uu, vv;
+                        if (triangleSolve(r0, r1, e2z, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), tt, uu, vv)) {
+                            t = tt;
+                            u = uu;
+                            v = vv;
                         }
                     }
+                    // a rejected or absent triangle is stored as t = -1, which the owner's "t < 0" test discards
+                    tBuf[rr * 8 + k] = t;
+                    uvBuf[rr * 8 + k] = make_float2(u, v);
                 }
-                triNext += RT_TRI_BATCH;
-                if (ANY && hitAny)
-                    mode = MODE_DONE;
-                else if (triNext >= triEnd)
-                    mode = MODE_POP;
+                __syncthreads();
+                if (part) {
+                    // cudaTracer/Mesh.cuh:141-146 + 205-208: leaf triangles in order; a hit needs t >= 0 and t <= reach,
+                    // so a later hit at equal t replaces an earlier one
+                    const float4 ta = reinterpret_cast<const float4*>(tBuf)[2 * rank], tb = reinterpret_cast<const float4*>(tBuf)[2 * rank + 1];
+                    const float ts[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+                    int win = -1;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const bool acc = !(ts[k] < 0.0f) && !(tMax < ts[k]) && !(ANY && win >= 0);
+                        tMax = acc ? ts[k] : tMax;
+                        win = acc ? k : win;
+                    }
+                    const unsigned left = end - next;
+                    if (COUNT) cTri += (ANY && win >= 0) ? (unsigned)win + 1u : (left < 8u ? left : 8u);
+                    if (win >= 0) {
+                        const float2 uv = uvBuf[rank * 8 + win];
+                        hu = uv.x;
+                        hv = uv.y;
+                        hTri = (int)(next + (unsigned)win);
+                        hShape = HIT_PENDING;
+                    }
+                    const unsigned nn = next + 8u;
+                    cur = (ANY && win >= 0) ? CUR_DONE : (nn >= end ? CUR_POP : (TAG_TRI | nn));
+                }
+            } else if (nodeMask != 0ull) {
+                // ========================= node step ==========================
+                if (COUNT) {
+                    wNodeSteps++;
+                    wNodeLanes += __popcll(nodeMask);
+                }
+                if ((int)cur >= 0) {
+                    const float4* p = blob4 + ((size_t)RT_REF_PAIR_UNITS(cur) << 2);
+                    const float4 L0 = p[0], L1 = p[1], L2 = p[2], L3 = p[3];
+                    const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+                    float t0, t1;
+                    const bool g0 = boxSlabs(L0, L1, o, inv, nx, ny, nz, t0);
+                    const bool g1 = boxSlabs(L2, L3, o, inv, nx, ny, nz, t1);
+                    const unsigned axis = RT_REF_AXIS(cur);
+                    const bool single = axis == RT_REF_ROOT_AXIS;  // a root record: there is no sibling
+                    // cudaTracer/Mesh.cuh:155-161: with a negative direction along the split axis the
+                    // second child is nearer; the other one waits on the stack
+                    const bool negAxis = !single && (axis == 0 ? nx : (axis == 1 ? ny : nz));
+                    const unsigned nearRef = __float_as_uint(negAxis ? L3.z : L1.z);
+                    const unsigned farRef = __float_as_uint(negAxis ? L1.z : L3.z);
+                    const bool nearGeo = negAxis ? g1 : g0, farGeo = negAxis ? g0 : g1;
+                    const float nearT = negAxis ? t1 : t0, farT = negAxis ? t0 : t1;
+                    const bool farHit = !single && farGeo && farT < tMax;
+                    const bool doPush = COUNT ? !single : farHit;
+                    // the entry is written in any case (above the top of the stack it is harmless), which
+                    // keeps the common path free of branches
+                    const uint2 e = make_uint2(farRef, __float_as_uint(farHit ? farT : kInf));
+                    const int slot = sp < ldsEntries ? sp : ldsEntries;
+                    stk[slot * kWave] = e;
+                    if (doPush && sp >= ldsEntries) gstk[(size_t)(sp - ldsEntries) * kWave] = e;
+                    sp += doPush ? 1 : 0;
+                    if (COUNT) cNode++;
+                    enter(nearRef);
+                    if (!(nearGeo && nearT < tMax)) cur = CUR_POP;
+                }
             }
-            if (mode == MODE_SHAPE) {
-                curShape = shapeNext++;
-                const DevShape& s = shapes[curShape];
+            // ================= scene-leaf shapes (per lane) ==================
+            if (cur >= TAG_SHAPE && cur < STACK_MESH_EXIT) {
+                const unsigned idx = cur & IDX_MASK;
+                const unsigned nextShape = idx + 1u;
+                const DevShape& s = shapes[idx];
                 if (s.kind == RT_SHAPE_SPHERE) {
                     if (COUNT) cSphere++;
-                    if (sphereHit(s, o, d, tMax)) {
-                        hShape = curShape;
-                        hitAny = true;
-                        if (ANY) mode = MODE_DONE;
-                    }
-                    if (mode != MODE_DONE && shapeNext == shapeEnd) mode = MODE_POP;
+                    const bool hit = sphereHit(s, o, d, tMax);
+                    if (hit) hShape = (int)idx;
+                    cur = (ANY && hit) ? CUR_DONE : (nextShape < end ? (TAG_SHAPE | nextShape) : CUR_POP);
                 } else {
                     // cudaTracer/Mesh.cuh:115-117 + cudaTracer/Mat.cuh:127-149: the origin is
                     // divided by w, the direction is neither translated nor renormalised
@@ -521,8 +541,15 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     const float4* M = reinterpret_cast<const float4*>(m->inv);
                     const float4 m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
                     if (COUNT) cMesh++;
-                    wo = o;
-                    wd = d;
+                    // the world-space ray and the rest of the scene leaf wait on the stack
+                    push(__float_as_uint(o.x), __float_as_uint(o.y));
+                    push(__float_as_uint(o.z), __float_as_uint(d.x));
+                    push(__float_as_uint(d.y), __float_as_uint(d.z));
+                    push(__float_as_uint(inv.x), __float_as_uint(inv.y));
+                    push(__float_as_uint(inv.z), 0u);
+                    push(TAG_SHAPE | nextShape, end);
+                    push(STACK_MESH_EXIT, idx);
+                    const V3 wo = o, wd = d;
                     const float pa = ((wo.x * m0.x + wo.y * m1.x) + wo.z * m2.x) + m3.x;
                     const float pb = ((wo.x * m0.y + wo.y * m1.y) + wo.z * m2.y) + m3.y;
                     const float pc = ((wo.x * m0.z + wo.y * m1.z) + wo.z * m2.z) + m3.z;
@@ -531,68 +558,51 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     d = mk((wd.x * m0.x + wd.y * m1.x) + wd.z * m2.x, (wd.x * m0.y + wd.y * m1.y) + wd.z * m2.y,
                            (wd.x * m0.z + wd.y * m1.z) + wd.z * m2.z);
                     inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                    nx = inv.x < 0;
-                    ny = inv.y < 0;
-                    nz = inv.z < 0;
-                    inBlas = true;
-                    blasHit = false;
-                    base = sp;
-                    nodes = reinterpret_cast<const float4*>(P.blob + m->offNodes);
-                    tris = reinterpret_cast<const float4*>(P.blob + m->offTriRecords);
-                    if (useMeshBvhs) {
-                        RT_ROOT();
-                    } else {
-                        triNext = 0;
-                        triEnd = m->triangleCnt;
-                        mode = MODE_TRI;
-                    }
+                    // cudaTracer/Mesh.cuh:137-138: root box test, or all triangles in order without a BVH
+                    cur = useMeshBvhs ? m->rootRef : (TAG_TRI | m->recordBase);
+                    end = m->recordBase + (unsigned)m->triangleCnt;
                 }
             }
-            while (mode == MODE_POP) {
-                if (sp > base) {
-                    --sp;
-                    const uint2 e = sp < ldsEntries ? stk[sp * kWave] : gstk[(size_t)(sp - ldsEntries) * kWave];
-                    if (COUNT) cNode++;
-                    if (__uint_as_float(e.y) < tMax) RT_ENTER(e.x);
-                } else if (inBlas) {
-                    // mesh walk finished: back to world space (t is shared between the spaces)
-                    inBlas = false;
-                    o = wo;
-                    d = wd;
-                    inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                    nx = inv.x < 0;
-                    ny = inv.y < 0;
-                    nz = inv.z < 0;
-                    nodes = sceneNodes;
-                    base = 0;
-                    if (blasHit) {
-                        hShape = curShape;
-                        hitAny = true;
-                    }
-                    if (shapeNext < shapeEnd) mode = MODE_SHAPE;
+            // ========================= stack pops ============================
+            while (cur == CUR_POP) {
+                if (sp == 0) {
+                    cur = CUR_DONE;
                 } else {
-                    mode = MODE_DONE;
+                    const uint2 e = pop();
+                    if (e.x == STACK_MESH_EXIT) {
+                        // mesh walk finished: back to world space (t is shared between the spaces)
+                        if (hShape == HIT_PENDING) hShape = (int)e.y;
+                        const uint2 c = pop(), e4 = pop(), e3 = pop(), e2 = pop(), e1 = pop(), e0 = pop();
+                        o = mk(__uint_as_float(e0.x), __uint_as_float(e0.y), __uint_as_float(e1.x));
+                        d = mk(__uint_as_float(e1.y), __uint_as_float(e2.x), __uint_as_float(e2.y));
+                        inv = mk(__uint_as_float(e3.x), __uint_as_float(e3.y), __uint_as_float(e4.x));
+                        end = c.y;
+                        cur = (c.x & IDX_MASK) < c.y ? c.x : CUR_POP;
+                    } else {
+                        if (COUNT) cNode++;
+                        if (__uint_as_float(e.y) < tMax) enter(e.x);
+                    }
                 }
             }
             // keep going while most lanes still work; once the queue is dry, until all are done
-            const unsigned long long busy = __ballot(item >= 0 && mode != MODE_DONE);
+            const unsigned long long busy = __ballot(cur != CUR_DONE);
             if (busy == 0ull) break;
             if (!exhausted && __popcll(busy) <= kWave - RT_REFILL_LANES && __ballot(item >= 0) != busy) break;
         }
 
-        // ---- finished lanes publish their result and become idle ----------
-        if (item >= 0 && mode == MODE_DONE) {
+        // ---- finished lanes publish their result and give up their ray -----
+        if (item >= 0 && cur == CUR_DONE) {
             if (ANY) {
-                P.vis[item] = hitAny ? 0 : 1;
+                P.vis[item] = hShape != -1 ? 0 : 1;
             } else {
-                P.hit[item] = make_float4(tMax, hu, hv, __int_as_float(hitAny ? hShape : -1));
-                P.hitTri[item] = hTri;
+                int tri = hTri;
+                if (hShape >= 0 && shapes[hShape].kind == RT_SHAPE_MESH) tri -= (int)meshes[shapes[hShape].meshIdx].recordBase;
+                P.hit[item] = make_float4(tMax, hu, hv, __int_as_float(hShape >= 0 ? hShape : -1));
+                P.hitTri[item] = tri;
             }
             item = -1;
         }
     }
-#undef RT_ENTER
-#undef RT_ROOT
 
     if (COUNT && P.counters) {
         unsigned vals[6] = {cNode, cTri, cSphere, cMesh, cRays, cPrimary};
@@ -968,28 +978,40 @@ __global__ void advanceKernel(const FrameParams P, const int level) {
     P.ctl[CTL_DIFFUSE_CNT] = 0;
 }
 
-template <bool ANY, bool COUNT>
-void launchTrace(const FrameParams& p, int level, int cuCount, hipStream_t s) {
-    const size_t lds = (size_t)p.stackLds * kWave * sizeof(uint2);
-    hipLaunchKernelGGL((traceKernel<ANY, COUNT>), dim3(p.traceWaves), dim3(kWave), lds, s, p, level);
-}
-
+// Resident wavefronts per CU of one trace-kernel variant (register and LDS limits), cached per LDS size.
 template <bool ANY, bool COUNT>
 int wavesPerCu(size_t lds) {
-    int perCu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, traceKernel<ANY, COUNT>, kWave, lds) != hipSuccess || perCu < 1) perCu = 8;
-    return perCu > 32 ? 32 : perCu;
+    static size_t cachedLds = ~(size_t)0;
+    static int cached = 0;
+    if (lds != cachedLds) {
+        int perCu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, traceKernel<ANY, COUNT>, kWave, lds) != hipSuccess || perCu < 1) perCu = 8;
+        cached = perCu > 32 ? 32 : perCu;
+        cachedLds = lds;
+        if (getenv("RT_TRACE_DEBUG")) fprintf(stderr, "traceKernel<%d,%d>: %d resident wavefronts per CU with %zu B LDS\n", (int)ANY, (int)COUNT, cached, lds);
+    }
+    return cached;
+}
+
+// The grid is persistent: exactly as many wavefronts as stay resident for this variant, capped by
+// p.traceWaves (which also sizes the stack spill buffer).
+template <bool ANY, bool COUNT>
+void launchTrace(const FrameParams& p, int level, int cuCount, hipStream_t s) {
+    const size_t lds = traceLdsBytes(p.stackLds);
+    int waves = wavesPerCu<ANY, COUNT>(lds) * cuCount;
+    if (waves > p.traceWaves) waves = p.traceWaves;
+    hipLaunchKernelGGL((traceKernel<ANY, COUNT>), dim3(waves), dim3(kWave), lds, s, p, level);
 }
 
 }  // namespace
 
 int rtk_trace_waves_per_cu(int stackLds) {
-    const size_t lds = (size_t)stackLds * kWave * sizeof(uint2);
-    // one grid size for all four variants: the smallest residency, so that every wave of the grid is resident
+    const size_t lds = traceLdsBytes(stackLds);
+    // the largest residency of the four variants: each launch takes its own, this one sizes the spill buffer
     int w = wavesPerCu<false, false>(lds);
-    w = w < wavesPerCu<true, false>(lds) ? w : wavesPerCu<true, false>(lds);
-    w = w < wavesPerCu<false, true>(lds) ? w : wavesPerCu<false, true>(lds);
-    w = w < wavesPerCu<true, true>(lds) ? w : wavesPerCu<true, true>(lds);
+    w = w > wavesPerCu<true, false>(lds) ? w : wavesPerCu<true, false>(lds);
+    w = w > wavesPerCu<false, true>(lds) ? w : wavesPerCu<false, true>(lds);
+    w = w > wavesPerCu<true, true>(lds) ? w : wavesPerCu<true, true>(lds);
     return w;
 }
 

@@ -147,7 +147,9 @@ int treeDepth(const RtLinearNode* nodes, int nodeCnt, int primCnt, int* maxLeafP
 
 // Re-lays a depth-first LinearNode tree out as sibling pairs (see rt_device_format.h).
 // `out` receives 32-byte records {bbmin, bbmax, ref, 0}; its size is 2 * (interior nodes + 1).
-int pairLayout(const RtLinearNode* nodes, std::vector<RtLinearNode>& out, std::string* err) {
+// References are written relative to this tree (pair index / 2, primitive index within the
+// tree's primitive list) and made absolute by relocateRefs once the blob offsets are known.
+int pairLayout(const RtLinearNode* nodes, std::vector<RtLinearNode>& out, uint32_t leafTag, std::string* err) {
     struct Item {
         int src, dst;
     };
@@ -161,14 +163,14 @@ int pairLayout(const RtLinearNode* nodes, std::vector<RtLinearNode>& out, std::s
         RtLinearNode rec = n;
         uint32_t ref;
         if (n.primCnt > 0) {
-            if (n.primCnt > RT_REF_MAX_LEAF_PRIMS || n.offset >= RT_REF_MAX_PRIMS) {
-                *err = "BVH leaf too large for the packed node reference (more than 127 primitives in a leaf or 16M primitives)";
+            if (n.primCnt > RT_REF_MAX_LEAF_PRIMS) {
+                *err = "BVH leaf too large for the packed node reference (more than 63 primitives in a leaf)";
                 return RT_ERR_LIMIT;
             }
-            ref = RT_REF_LEAF | ((uint32_t)n.primCnt << 24) | (uint32_t)n.offset;
+            ref = RT_REF_LEAF | leafTag | ((uint32_t)n.primCnt << 24) | (uint32_t)n.offset;
         } else {
             const size_t pair = out.size();
-            if (pair / 2 >= (1u << 29)) {
+            if (pair / 2 >= (1u << 28)) {
                 *err = "BVH too large for the packed node reference";
                 return RT_ERR_LIMIT;
             }
@@ -183,6 +185,33 @@ int pairLayout(const RtLinearNode* nodes, std::vector<RtLinearNode>& out, std::s
         rec.axis = 0;
         rec.pad = 0;
         out[it.dst] = rec;
+    }
+    return RT_OK;
+}
+
+// Makes the references of a laid-out tree absolute: child pairs in 64-byte units from the blob
+// start (`unitBase` = blob offset of the tree / 64), leaf primitives shifted by `primBase`.
+int relocateRefs(std::vector<RtLinearNode>& recs, uint64_t unitBase, uint32_t primBase, std::string* err) {
+    for (size_t i = 0; i < recs.size(); ++i) {
+        if (i == 1) continue;  // padding next to the root
+        uint32_t ref;
+        std::memcpy(&ref, &recs[i].offset, 4);
+        if (RT_REF_IS_LEAF(ref)) {
+            const uint64_t first = (uint64_t)RT_REF_LEAF_FIRST(ref) + primBase;
+            if (first + RT_REF_LEAF_COUNT(ref) > (uint64_t)RT_REF_MAX_PRIMS) {
+                *err = "scene too large for the packed node reference (16M primitives)";
+                return RT_ERR_LIMIT;
+            }
+            ref = (ref & 0xff000000u) | (uint32_t)first;
+        } else {
+            const uint64_t unit = (uint64_t)RT_REF_PAIR_UNITS(ref) + unitBase;
+            if (unit >= (1u << 29)) {
+                *err = "scene blob too large for the packed node reference (32 GB)";
+                return RT_ERR_LIMIT;
+            }
+            ref = (ref & 0x60000000u) | (uint32_t)unit;
+        }
+        std::memcpy(&recs[i].offset, &ref, 4);
     }
     return RT_OK;
 }
@@ -222,9 +251,21 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
     hd.offLights = reserve((size_t)std::max(d->lightCnt, 1) * sizeof(RtLight));
     hd.offShapes = reserve((size_t)d->shapeCnt * sizeof(DevShape));
     std::vector<RtLinearNode> scenePairs;
-    if (int r = pairLayout(d->nodes, scenePairs, err)) return r;
+    if (int r = pairLayout(d->nodes, scenePairs, RT_REF_SHAPES, err)) return r;
     hd.offSceneNodes = reserve(scenePairs.size() * sizeof(RtLinearNode));
     hd.offMeshes = reserve((size_t)std::max(d->meshCnt, 1) * sizeof(DevMesh));
+    // one record array for all meshes (+8 spare records), so that a leaf can name its triangles absolutely
+    size_t recordCnt = 0;
+    for (int mi = 0; mi < d->meshCnt; ++mi) recordCnt += (size_t)std::max(d->meshes[mi].triangleCnt, 0);
+    if (recordCnt > (size_t)RT_REF_MAX_PRIMS) {
+        *err = "scene too large for the packed node reference (16M triangles)";
+        return RT_ERR_LIMIT;
+    }
+    hd.recordCnt = (uint32_t)recordCnt;
+    hd.offRecords = reserve((recordCnt + 8) * sizeof(TriRecord));
+    if (int r = relocateRefs(scenePairs, hd.offSceneNodes / 64, 0, err)) return r;
+    hd.sceneRootRef = (RT_REF_ROOT_AXIS << 29) | (uint32_t)(hd.offSceneNodes / 64);
+    uint32_t recordBase = 0;
 
     std::vector<DevMesh> meshes(std::max(d->meshCnt, 0));
     std::vector<std::vector<RtLinearNode>> meshPairs(std::max(d->meshCnt, 0));
@@ -244,10 +285,13 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
         dm.triangleCnt = m.triangleCnt;
         dm.nodeCnt = m.nodeCnt;
         dm.vertexCnt = m.vertexCnt;
-        if (int r = pairLayout(m.nodes, meshPairs[mi], err)) return r;
+        if (int r = pairLayout(m.nodes, meshPairs[mi], 0u, err)) return r;
         dm.offNodes = reserve(meshPairs[mi].size() * sizeof(RtLinearNode));
-        // spare records: the kernel fetches up to four triangle records per step
-        dm.offTriRecords = reserve(((size_t)m.triangleCnt + 4) * sizeof(TriRecord));
+        dm.recordBase = recordBase;
+        dm.offTriRecords = hd.offRecords + (uint64_t)recordBase * sizeof(TriRecord);
+        if (int r = relocateRefs(meshPairs[mi], dm.offNodes / 64, recordBase, err)) return r;
+        dm.rootRef = (RT_REF_ROOT_AXIS << 29) | (uint32_t)(dm.offNodes / 64);
+        recordBase += (uint32_t)m.triangleCnt;
         dm.offVertices = reserve((size_t)m.vertexCnt * sizeof(RtVertex));
         const RtTexture* tex[3] = {&m.diffuse, &m.normals, &m.specular};
         for (int k = 0; k < 3; ++k) {
@@ -259,8 +303,8 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
             dm.offTex[k] = reserve((size_t)tex[k]->width * tex[k]->height * 4);
         }
     }
-    if (hd.sceneDepth + hd.maxMeshDepth + 1 > RT_STACK_ENTRIES) {
-        *err = "BVH too deep for the kernel's traversal stack (scene depth + mesh depth + 1 > RT_STACK_ENTRIES)";
+    if (hd.sceneDepth + hd.maxMeshDepth + 1 + RT_MESH_ENTRY_SLOTS > RT_STACK_ENTRIES) {
+        *err = "BVH too deep for the kernel's traversal stack (scene depth + mesh depth + 8 > RT_STACK_ENTRIES)";
         return RT_ERR_LIMIT;
     }
     hd.totalBytes = alignUp(cursor);
@@ -365,7 +409,7 @@ int ensureWorkspace(rt_ctx* ctx, int nodeCap, int slots, int lights, size_t spil
 int checkHeader(rt_ctx* ctx, const BlobHeader& hd, size_t bytes) {
     if (hd.magic != RT_BLOB_MAGIC || hd.version != RT_BLOB_VERSION) return fail(ctx, RT_ERR_INVALID, "not a scene blob");
     if (hd.totalBytes != bytes) return fail(ctx, RT_ERR_INVALID, "scene blob size mismatch");
-    if (hd.sceneDepth + hd.maxMeshDepth + 1 > RT_STACK_ENTRIES) return fail(ctx, RT_ERR_LIMIT, "scene blob exceeds the traversal stack");
+    if (hd.sceneDepth + hd.maxMeshDepth + 1 + RT_MESH_ENTRY_SLOTS > RT_STACK_ENTRIES) return fail(ctx, RT_ERR_LIMIT, "scene blob exceeds the traversal stack");
     return RT_OK;
 }
 
@@ -649,7 +693,6 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     if (opts->maxDepth < 0 || opts->maxDepth > RT_MAX_DEPTH)
         return fail(ctx, RT_ERR_LIMIT, "maxDepth %d outside 0..%d", opts->maxDepth, RT_MAX_DEPTH);
     const BlobHeader& hd = scene->header;
-    if (!opts->useSceneBvh && hd.maxMeshDepth > RT_STACK_ENTRIES) return fail(ctx, RT_ERR_LIMIT, "mesh BVH too deep");
 
     FrameParams p;
     std::memset(&p, 0, sizeof p);
@@ -678,7 +721,9 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     const int secondary = hd.hasSecondary ? 1 : 0;
     const int budget = secondary && opts->maxDepth > 0 ? ctx->pathBudget : 1;
     if (myTiles * RT_TILE * RT_TILE * budget > 0x7fffffffLL / 4) return fail(ctx, RT_ERR_LIMIT, "frame too large for 32-bit node indices");
-    p.stackEntries = hd.sceneDepth + hd.maxMeshDepth + 1;
+    p.stackEntries = hd.sceneDepth + hd.maxMeshDepth + 1 + RT_MESH_ENTRY_SLOTS;
+    p.sceneRootRef = hd.sceneRootRef;
+    p.offRecords = hd.offRecords;
     p.stackLds = std::min(p.stackEntries, ctx->ldsStack);
 
     if (int r = bind(ctx)) return r;

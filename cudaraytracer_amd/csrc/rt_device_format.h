@@ -6,8 +6,8 @@
 // copied between GPUs (RCCL broadcast) and used as is.
 //
 //   [BlobHeader 256 B][lights][DevShape x shapeCnt][scene nodes 32 B each]
-//   [DevMesh x meshCnt] then per mesh: [mesh nodes 32 B][triangle records 48 B]
-//   [vertices 56 B][diffuse RGBA8][normals RGBA8][specular RGBA8]
+//   [DevMesh x meshCnt][triangle records 48 B, all meshes back to back]
+//   then per mesh: [mesh nodes 32 B][vertices 56 B][diffuse RGBA8][normals RGBA8][specular RGBA8]
 //
 // Every section starts on a 256-byte boundary.
 //
@@ -19,6 +19,9 @@
 //   {bbmin[3], bbmax[3], ref, 0}
 // with `ref` describing the node itself (see the RT_REF_* macros): a leaf names
 // its primitive range, an interior node names its child pair and split axis.
+// References are ABSOLUTE within the blob (child pairs in 64-byte units from the
+// blob start, triangles as indices into the one record array, shapes as indices
+// into the shape table), so a traversal needs no per-tree base pointers.
 // Box values, split axes and leaf contents are untouched, so every box test
 // and the near/far visiting order are those of the original tree.
 //
@@ -37,20 +40,27 @@
 #include "../../include/rt_capi.h"
 
 #define RT_BLOB_MAGIC 0x52544246u /* "RTBF" */
-#define RT_BLOB_VERSION 2u
+#define RT_BLOB_VERSION 3u
 #define RT_TILE 8 /* 8x8 pixels = 64 level-0 path nodes */
+#define RT_MESH_ENTRY_SLOTS 7 /* traversal-stack entries that hold the world-space ray while a mesh is walked */
 
 /* 32-bit node reference.
- *   leaf:     bit 31 set | primitive count (7 bits) << 24 | first primitive (24 bits)
- *   interior: split axis (2 bits) << 29 | index of the child pair / 2 (29 bits) */
+ *   leaf:     bit 31 set | bit 30 set for a scene-BVH leaf (shapes), clear for a mesh-BVH leaf (triangles)
+ *             | primitive count (6 bits) << 24 | first primitive (24 bits)
+ *   interior: split axis (2 bits) << 29 | blob offset of the child pair / 64 (29 bits)
+ *             axis value 3 marks the pseudo reference to a tree's root record: only the first
+ *             record of the pair is a node, and it is the "near child". */
 #define RT_REF_LEAF 0x80000000u
-#define RT_REF_MAX_LEAF_PRIMS 127
-#define RT_REF_MAX_PRIMS (1 << 24)
+#define RT_REF_SHAPES 0x40000000u
+#define RT_REF_TAG_MASK 0xC0000000u
+#define RT_REF_MAX_LEAF_PRIMS 63
+#define RT_REF_MAX_PRIMS ((1 << 24) - 16)
 #define RT_REF_IS_LEAF(r) (((r)&RT_REF_LEAF) != 0u)
-#define RT_REF_LEAF_COUNT(r) (((r) >> 24) & 0x7fu)
+#define RT_REF_LEAF_COUNT(r) (((r) >> 24) & 0x3fu)
 #define RT_REF_LEAF_FIRST(r) ((r)&0xffffffu)
 #define RT_REF_AXIS(r) (((r) >> 29) & 3u)
-#define RT_REF_PAIR(r) (((r)&0x1fffffffu) << 1)
+#define RT_REF_ROOT_AXIS 3u
+#define RT_REF_PAIR_UNITS(r) ((r)&0x1fffffffu) /* 64-byte units from the blob start */
 
 struct BlobHeader {
     uint32_t magic;
@@ -68,7 +78,10 @@ struct BlobHeader {
     uint64_t offShapes;
     uint64_t offSceneNodes;
     uint64_t offMeshes;
-    uint8_t reserved[256 - 80];
+    uint64_t offRecords;    // triangle records of all meshes
+    uint32_t sceneRootRef;  // pseudo reference to the scene BVH's root record
+    uint32_t recordCnt;
+    uint8_t reserved[256 - 96];
 };
 
 // One shape, 64 bytes (the reference's Shape is 232 B with the Mesh embedded).
@@ -99,7 +112,9 @@ struct DevMesh {
     int32_t triangleCnt;
     int32_t nodeCnt;
     int32_t vertexCnt;
-    int32_t pad[8];
+    uint32_t rootRef;     // pseudo reference to the mesh BVH's root record
+    uint32_t recordBase;  // index of the mesh's first triangle record in the blob's record array
+    int32_t pad[6];
 };
 
 // Triangle record, 48 bytes: v0 and the two edges exactly as the reference's
@@ -155,11 +170,13 @@ struct FrameParams {
     int32_t nodeCap;                         // capacity of the per-node arrays
     int32_t stackEntries;                    // per-lane traversal stack entries needed (8 bytes each)
     int32_t stackLds;                        // how many of them live in LDS; the rest in stackSpill
+    uint32_t sceneRootRef;
+    uint64_t offRecords;
     int32_t traceWaves;                      // wavefronts of the persistent trace kernels
     // workspace (device pointers)
     uint32_t* ctl;          // CTL_WORDS
     float4* hit;            // [nodeCap] {t, u, v, shape slot as int bits (-1 miss, -2 outside the frame)}
-    int32_t* hitTri;        // [nodeCap] triangle record of the hit
+    int32_t* hitTri;        // [nodeCap] triangle of the hit (index within its mesh)
     float4* color;          // [nodeCap] radiance returned by the node
     float4* secRay;         // [2 * (nodeCap - slots)] origin, direction of nodes beyond level 0
     int32_t* child;         // [nodeCap] first child node (mirror: 1 child, glass: 2 consecutive)

@@ -14,35 +14,36 @@ LEAF = 0x80000000
 
 
 def header(blob):
-    f = struct.unpack_from("<IIQ8i4Q", blob, 0)
+    f = struct.unpack_from("<IIQ8i5QII", blob, 0)
     names = ["magic", "version", "totalBytes", "lightCnt", "shapeCnt", "meshCnt", "sceneNodeCnt", "sceneDepth", "maxMeshDepth",
-             "hasSecondary", "maxLeafShapes", "offLights", "offShapes", "offSceneNodes", "offMeshes"]
+             "hasSecondary", "maxLeafShapes", "offLights", "offShapes", "offSceneNodes", "offMeshes", "offRecords", "sceneRootRef",
+             "recordCnt"]
     return dict(zip(names, f))
 
 
-def pairs_to_dfs(blob, off):
-    """Walks a sibling-pair tree in the input's order (node, first child subtree, second child subtree) and returns
-    [(bbmin, bbmax, is_leaf, first, count, axis)] so it can be compared with the depth-first input."""
-    recs = np.frombuffer(blob, dtype=np.uint8, offset=off)
+def pairs_to_dfs(blob, root_ref, prim_base, shapes_leaf):
+    """Walks a sibling-pair tree from its root pseudo reference in the input's order (node, first child subtree, second
+    child subtree) and returns [(bbmin, bbmax, is_leaf, first, count, axis)] so it can be compared with the depth-first input."""
     out = []
+    assert (root_ref >> 29) == 3  # pseudo reference to a root record
 
-    def rec(i):
-        f = np.frombuffer(recs[32 * i: 32 * i + 24].tobytes(), dtype=np.float32)
-        ref = struct.unpack_from("<I", recs[32 * i + 24: 32 * i + 28].tobytes())[0]
+    def rec(byte_off):
+        f = np.frombuffer(blob[byte_off: byte_off + 24].tobytes(), dtype=np.float32)
+        ref = struct.unpack_from("<I", blob[byte_off + 24: byte_off + 28].tobytes())[0]
         return f, ref
 
-    def walk(i):
-        f, ref = rec(i)
+    def walk(byte_off):
+        f, ref = rec(byte_off)
         if ref & LEAF:
-            out.append((f[:3].tolist(), f[3:].tolist(), True, ref & 0xFFFFFF, (ref >> 24) & 0x7F, 0))
+            assert bool(ref & 0x40000000) == shapes_leaf
+            out.append((f[:3].tolist(), f[3:].tolist(), True, (ref & 0xFFFFFF) - prim_base, (ref >> 24) & 0x3F, 0))
         else:
             out.append((f[:3].tolist(), f[3:].tolist(), False, 0, 0, (ref >> 29) & 3))
-            pair = (ref & 0x1FFFFFFF) << 1
-            assert pair % 2 == 0 and pair >= 2
+            pair = (ref & 0x1FFFFFFF) * 64  # absolute: 64-byte units from the blob start
             walk(pair)
-            walk(pair + 1)
+            walk(pair + 32)
 
-    walk(0)
+    walk((root_ref & 0x1FFFFFFF) * 64)
     return out
 
 
@@ -63,19 +64,26 @@ def test_blob_holds_the_scene(rtlib, name, size, tight):
     h = header(blob)
     assert h["magic"] == 0x52544246 and h["totalBytes"] == len(blob) and len(blob) % 256 == 0
     assert (h["lightCnt"], h["shapeCnt"], h["meshCnt"], h["sceneNodeCnt"]) == (d.lightCnt, d.shapeCnt, d.meshCnt, d.nodeCnt)
-    for k in ("offLights", "offShapes", "offSceneNodes", "offMeshes"):
+    assert h["version"] == 3 and h["recordCnt"] == sum(d.meshes[i].triangleCnt for i in range(d.meshCnt))
+    for k in ("offLights", "offShapes", "offSceneNodes", "offMeshes", "offRecords"):
         assert h[k] % 256 == 0 and h[k] < len(blob)
     # lights verbatim
     assert blob[h["offLights"]: h["offLights"] + 28 * d.lightCnt].tobytes() == C.string_at(d.lights, 28 * d.lightCnt)
     # scene BVH: same boxes, leaves and split axes in the same depth-first order
-    assert pairs_to_dfs(blob, h["offSceneNodes"]) == dfs_input(d.nodes, d.nodeCnt)
+    assert (h["sceneRootRef"] & 0x1FFFFFFF) * 64 == h["offSceneNodes"]
+    assert pairs_to_dfs(blob, h["sceneRootRef"], 0, True) == dfs_input(d.nodes, d.nodeCnt)
+    record_base = 0
     # every mesh BVH likewise, and triangle records = (v0, v1 - v0, v2 - v0, indices) in fp32
     for mi in range(d.meshCnt):
         m = d.meshes[mi]
-        dm = struct.unpack_from("<16f6Q9i4i", blob, h["offMeshes"] + 192 * mi)
+        dm = struct.unpack_from("<16f6Q9i3i2I", blob, h["offMeshes"] + 192 * mi)
         off_nodes, off_tris, off_verts = dm[16], dm[17], dm[18]
         assert dm[31:34] == (m.triangleCnt, m.nodeCnt, m.vertexCnt)
-        assert pairs_to_dfs(blob, off_nodes) == dfs_input(m.nodes, m.nodeCnt)
+        root_ref, rec_base = dm[34], dm[35]
+        assert rec_base == record_base and off_tris == h["offRecords"] + 48 * rec_base
+        record_base += m.triangleCnt
+        assert (root_ref & 0x1FFFFFFF) * 64 == off_nodes
+        assert pairs_to_dfs(blob, root_ref, rec_base, False) == dfs_input(m.nodes, m.nodeCnt)
         assert blob[off_verts: off_verts + 56 * m.vertexCnt].tobytes() == C.string_at(m.vertices, 56 * m.vertexCnt)
         rec = np.frombuffer(blob, dtype=np.float32, count=12 * m.triangleCnt, offset=off_tris).reshape(-1, 12)
         idx = np.frombuffer(C.string_at(m.triangles, 12 * m.triangleCnt), dtype=np.int32).reshape(-1, 3)
@@ -133,7 +141,7 @@ def test_malformed_scenes_are_rejected(rtlib):
 
 
 def test_leaf_larger_than_the_reference_field_allows_is_a_limit_error(rtlib):
-    """A one-leaf BVH over 200 triangles (what the reference builds for coincident centroids) exceeds the 7-bit
+    """A one-leaf BVH over 200 triangles (what the reference builds for coincident centroids) exceeds the 6-bit
     leaf count of the packed node reference."""
     s = rt.HostScene("soup", 32, 32, 200, 1, 0)
     d = s.desc.contents
