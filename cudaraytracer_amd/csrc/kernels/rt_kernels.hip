@@ -40,7 +40,7 @@ constexpr unsigned kChunk = RT_CHUNK;  // rays a wavefront takes from the global
 #define RT_REFILL_LANES 8  // a wavefront refills once this many lanes have finished their rays
 #endif
 #ifndef RT_TRI_LANES
-#define RT_TRI_LANES 20  // a triangle phase starts once this many lanes wait in a leaf
+#define RT_TRI_LANES 8  // a triangle phase starts once this many lanes wait in a leaf
 #endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1  // __launch_bounds__ waves per SIMD for the trace kernel
@@ -219,9 +219,10 @@ constexpr unsigned STACK_MESH_EXIT = 0xFFFFFFFDu;  // stack marker: the mesh wal
 constexpr int HIT_PENDING = -3;                    // hShape while the hit mesh is still being walked
 
 #ifndef RT_TRI_PART
-#define RT_TRI_PART 32  // rays whose leaves are tested in one cooperative triangle phase (8 lanes each, 8 rays per round)
+#define RT_TRI_PART 16  // rays whose leaves are tested in one cooperative triangle phase (8 lanes each, 8 rays per round)
 #endif
 constexpr int kTriPart = RT_TRI_PART;
+static_assert(RT_MESH_ENTRY_SLOTS >= 6, "the mesh-entry save area holds six entries");
 constexpr size_t kTriLdsBytes = (size_t)kTriPart * (2 * sizeof(float4) + 8 * sizeof(float) + 8 * sizeof(float2));
 
 __host__ __device__ constexpr size_t traceLdsBytes(int stackLds) { return (size_t)(stackLds + 1) * kWave * sizeof(uint2) + kTriLdsBytes; }
@@ -280,8 +281,7 @@ __device__ __forceinline__ bool triangleSolve(const float4 r0, const float4 r1, 
 //
 // The stack (8 bytes per entry: node reference + entry distance) lives in LDS,
 // one column per lane, with a global-memory continuation for deep entries; it
-// is shared by the scene BVH and the mesh BVH.  While a mesh is walked it also
-// keeps the world-space ray (RT_MESH_ENTRY_SLOTS entries under a marker).
+// is shared by the scene BVH and the mesh BVH; a marker entry separates the two.
 // Visiting order, near/far choice and the <=-tie rule are the reference's, so
 // results do not depend on which lane or wavefront a ray lands in.
 //
@@ -294,13 +294,18 @@ template <bool ANY, bool COUNT>
 __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FrameParams P, const int level) {
     extern __shared__ uint2 s_dyn[];
     const int lane = threadIdx.x;
-    const int ldsEntries = P.stackLds;
-    uint2* const stk = s_dyn + lane;  // entry e of this lane: stk[e * 64]; entry ldsEntries is a write-only dump slot
-    float4* const rayBuf = reinterpret_cast<float4*>(s_dyn + (size_t)(ldsEntries + 1) * kWave);  // [kTriPart][2]
-    float* const tBuf = reinterpret_cast<float*>(rayBuf + 2 * kTriPart);                         // [kTriPart][8]
-    float2* const uvBuf = reinterpret_cast<float2*>(tBuf + 8 * kTriPart);                        // [kTriPart][8]
-    // entries beyond the LDS part of the stack live in this wavefront's slice of a global array
-    uint2* const gstk = P.stackSpill + ((size_t)blockIdx.x * (size_t)(P.stackEntries - P.stackLds)) * kWave + lane;
+    // The top of each lane's traversal stack is a ring of ringN (a power of two) entries in LDS: entry e lives in
+    // stk[(e & ringMask) * 64].  Entries [lo, sp) are in the ring, older ones [0, lo) in this wavefront's slice of a
+    // global array, so global memory is touched only when a walk gets more than ringN entries ahead of itself.
+    // Slot ringN of the LDS column is a write-only dump slot.
+    const int ringN = P.stackLds, ringMask = ringN - 1;
+    uint2* const stk = s_dyn + lane;
+    float4* const rayBuf = reinterpret_cast<float4*>(s_dyn + (size_t)(ringN + 1) * kWave);  // [kTriPart][2]
+    float* const tBuf = reinterpret_cast<float*>(rayBuf + 2 * kTriPart);                    // [kTriPart][8]
+    float2* const uvBuf = reinterpret_cast<float2*>(tBuf + 8 * kTriPart);                   // [kTriPart][8]
+    uint2* const gstk = P.stackSpill + ((size_t)blockIdx.x * (size_t)(P.stackEntries + RT_MESH_ENTRY_SLOTS)) * kWave + lane;
+    // the world-space ray and the rest of the scene leaf wait here while a mesh is walked
+    uint2* const gsave = gstk + (size_t)P.stackEntries * kWave;
 
     const unsigned total = ANY ? P.ctl[CTL_DIFFUSE_CNT] * (unsigned)P.lightCnt : P.ctl[CTL_LEVEL_COUNT + level];
     const unsigned first = ANY ? 0u : P.ctl[CTL_LEVEL_START + level];
@@ -328,20 +333,25 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     V3 o = mk(0, 0, 0), d = mk(0, 0, 1), inv = mk(0, 0, 0);
     float tMax = 0.0f;
     unsigned cur = CUR_DONE, end = 0;
-    int sp = 0;
+    int sp = 0, lo = 0;  // stack entries [lo, sp) are in the LDS ring, [0, lo) in global memory
     int hShape = -1, hTri = -1;
     float hu = 0.0f, hv = 0.0f;
 
     auto push = [&](unsigned x, unsigned y) {
-        if (sp < ldsEntries)
-            stk[sp * kWave] = make_uint2(x, y);
-        else
-            gstk[(size_t)(sp - ldsEntries) * kWave] = make_uint2(x, y);
+        if (sp - lo >= ringN) {
+            gstk[(size_t)lo * kWave] = stk[(lo & ringMask) * kWave];
+            ++lo;
+        }
+        stk[(sp & ringMask) * kWave] = make_uint2(x, y);
         ++sp;
     };
     auto pop = [&]() -> uint2 {
         --sp;
-        return sp < ldsEntries ? stk[sp * kWave] : gstk[(size_t)(sp - ldsEntries) * kWave];
+        if (sp < lo) {
+            lo = sp;
+            return gstk[(size_t)sp * kWave];
+        }
+        return stk[(sp & ringMask) * kWave];
     };
     // enter the node described by reference r (its box test has passed)
     auto enter = [&](unsigned r) {
@@ -400,6 +410,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     hTri = -1;
                     hu = hv = 0.0f;
                     sp = 0;
+                    lo = 0;
                     // cudaTracer/Scene.cuh:38-39: the walk starts with the root's box test
                     cur = useSceneBvh ? P.sceneRootRef : TAG_SHAPE;
                     end = (unsigned)P.shapeCnt;
@@ -512,12 +523,15 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     const float nearT = negAxis ? t1 : t0, farT = negAxis ? t0 : t1;
                     const bool farHit = !single && farGeo && farT < tMax;
                     const bool doPush = COUNT ? !single : farHit;
-                    // the entry is written in any case (above the top of the stack it is harmless), which
-                    // keeps the common path free of branches
+                    // the entry is written in any case (above the top of the stack it is harmless; with a full
+                    // ring and nothing to push it goes to the dump slot), which keeps the common path free of branches
                     const uint2 e = make_uint2(farRef, __float_as_uint(farHit ? farT : kInf));
-                    const int slot = sp < ldsEntries ? sp : ldsEntries;
-                    stk[slot * kWave] = e;
-                    if (doPush && sp >= ldsEntries) gstk[(size_t)(sp - ldsEntries) * kWave] = e;
+                    const bool full = sp - lo >= ringN;
+                    if (doPush && full) {
+                        gstk[(size_t)lo * kWave] = stk[(lo & ringMask) * kWave];
+                        ++lo;
+                    }
+                    stk[((!doPush && full) ? ringN : (sp & ringMask)) * kWave] = e;
                     sp += doPush ? 1 : 0;
                     if (COUNT) cNode++;
                     enter(nearRef);
@@ -541,13 +555,12 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     const float4* M = reinterpret_cast<const float4*>(m->inv);
                     const float4 m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
                     if (COUNT) cMesh++;
-                    // the world-space ray and the rest of the scene leaf wait on the stack
-                    push(__float_as_uint(o.x), __float_as_uint(o.y));
-                    push(__float_as_uint(o.z), __float_as_uint(d.x));
-                    push(__float_as_uint(d.y), __float_as_uint(d.z));
-                    push(__float_as_uint(inv.x), __float_as_uint(inv.y));
-                    push(__float_as_uint(inv.z), 0u);
-                    push(TAG_SHAPE | nextShape, end);
+                    gsave[0 * kWave] = make_uint2(__float_as_uint(o.x), __float_as_uint(o.y));
+                    gsave[1 * kWave] = make_uint2(__float_as_uint(o.z), __float_as_uint(d.x));
+                    gsave[2 * kWave] = make_uint2(__float_as_uint(d.y), __float_as_uint(d.z));
+                    gsave[3 * kWave] = make_uint2(__float_as_uint(inv.x), __float_as_uint(inv.y));
+                    gsave[4 * kWave] = make_uint2(__float_as_uint(inv.z), 0u);
+                    gsave[5 * kWave] = make_uint2(TAG_SHAPE | nextShape, end);
                     push(STACK_MESH_EXIT, idx);
                     const V3 wo = o, wd = d;
                     const float pa = ((wo.x * m0.x + wo.y * m1.x) + wo.z * m2.x) + m3.x;
@@ -572,7 +585,8 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     if (e.x == STACK_MESH_EXIT) {
                         // mesh walk finished: back to world space (t is shared between the spaces)
                         if (hShape == HIT_PENDING) hShape = (int)e.y;
-                        const uint2 c = pop(), e4 = pop(), e3 = pop(), e2 = pop(), e1 = pop(), e0 = pop();
+                        const uint2 e0 = gsave[0 * kWave], e1 = gsave[1 * kWave], e2 = gsave[2 * kWave], e3 = gsave[3 * kWave],
+                                    e4 = gsave[4 * kWave], c = gsave[5 * kWave];
                         o = mk(__uint_as_float(e0.x), __uint_as_float(e0.y), __uint_as_float(e1.x));
                         d = mk(__uint_as_float(e1.y), __uint_as_float(e2.x), __uint_as_float(e2.y));
                         inv = mk(__uint_as_float(e3.x), __uint_as_float(e3.y), __uint_as_float(e4.x));

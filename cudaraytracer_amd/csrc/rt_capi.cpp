@@ -20,7 +20,7 @@
 #define RT_SUBFRAMES_DEFAULT 1
 #endif
 #ifndef RT_LDS_STACK_DEFAULT
-#define RT_LDS_STACK_DEFAULT 20
+#define RT_LDS_STACK_DEFAULT 8
 #endif
 
 namespace {
@@ -303,8 +303,8 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
             dm.offTex[k] = reserve((size_t)tex[k]->width * tex[k]->height * 4);
         }
     }
-    if (hd.sceneDepth + hd.maxMeshDepth + 1 + RT_MESH_ENTRY_SLOTS > RT_STACK_ENTRIES) {
-        *err = "BVH too deep for the kernel's traversal stack (scene depth + mesh depth + 8 > RT_STACK_ENTRIES)";
+    if (hd.sceneDepth + hd.maxMeshDepth + 2 > RT_STACK_ENTRIES) {
+        *err = "BVH too deep for the kernel's traversal stack (scene depth + mesh depth + 2 > RT_STACK_ENTRIES)";
         return RT_ERR_LIMIT;
     }
     hd.totalBytes = alignUp(cursor);
@@ -409,7 +409,7 @@ int ensureWorkspace(rt_ctx* ctx, int nodeCap, int slots, int lights, size_t spil
 int checkHeader(rt_ctx* ctx, const BlobHeader& hd, size_t bytes) {
     if (hd.magic != RT_BLOB_MAGIC || hd.version != RT_BLOB_VERSION) return fail(ctx, RT_ERR_INVALID, "not a scene blob");
     if (hd.totalBytes != bytes) return fail(ctx, RT_ERR_INVALID, "scene blob size mismatch");
-    if (hd.sceneDepth + hd.maxMeshDepth + 1 + RT_MESH_ENTRY_SLOTS > RT_STACK_ENTRIES) return fail(ctx, RT_ERR_LIMIT, "scene blob exceeds the traversal stack");
+    if (hd.sceneDepth + hd.maxMeshDepth + 2 > RT_STACK_ENTRIES) return fail(ctx, RT_ERR_LIMIT, "scene blob exceeds the traversal stack");
     return RT_OK;
 }
 
@@ -721,10 +721,12 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     const int secondary = hd.hasSecondary ? 1 : 0;
     const int budget = secondary && opts->maxDepth > 0 ? ctx->pathBudget : 1;
     if (myTiles * RT_TILE * RT_TILE * budget > 0x7fffffffLL / 4) return fail(ctx, RT_ERR_LIMIT, "frame too large for 32-bit node indices");
-    p.stackEntries = hd.sceneDepth + hd.maxMeshDepth + 1 + RT_MESH_ENTRY_SLOTS;
+    p.stackEntries = hd.sceneDepth + hd.maxMeshDepth + 2;
     p.sceneRootRef = hd.sceneRootRef;
     p.offRecords = hd.offRecords;
-    p.stackLds = std::min(p.stackEntries, ctx->ldsStack);
+    // the LDS part of the stack is a ring: a power of two
+    p.stackLds = 2;
+    while (p.stackLds * 2 <= ctx->ldsStack && p.stackLds < p.stackEntries) p.stackLds *= 2;
 
     if (int r = bind(ctx)) return r;
     if (ctx->wavesForLds != p.stackLds) {
@@ -749,7 +751,7 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
         totalNodes += q.nodeCap;
         totalSec += q.nodeCap - q.slots;
     }
-    const size_t spillPerSub = (size_t)p.traceWaves * (size_t)(p.stackEntries - p.stackLds) * 64 * 8;
+    const size_t spillPerSub = (size_t)p.traceWaves * (size_t)(p.stackEntries + RT_MESH_ENTRY_SLOTS) * 64 * 8;
     if (int r = ensureWorkspace(ctx, (int)totalNodes, (int)(totalNodes - totalSec), hd.lightCnt, std::max<size_t>(spillPerSub * nSubs, 256))) return r;
     const Workspace& w = ctx->ws;
     const size_t lc = (size_t)std::max(hd.lightCnt, 1);

@@ -42,7 +42,7 @@
 #define RT_BLOB_MAGIC 0x52544246u /* "RTBF" */
 #define RT_BLOB_VERSION 3u
 #define RT_TILE 8 /* 8x8 pixels = 64 level-0 path nodes */
-#define RT_MESH_ENTRY_SLOTS 7 /* traversal-stack entries that hold the world-space ray while a mesh is walked */
+#define RT_MESH_ENTRY_SLOTS 6 /* 8-byte slots per lane that hold the world-space ray while a mesh is walked */
 
 /* 32-bit node reference.
  *   leaf:     bit 31 set | bit 30 set for a scene-BVH leaf (shapes), clear for a mesh-BVH leaf (triangles)
@@ -169,7 +169,7 @@ struct FrameParams {
     int32_t slots;                           // tileCnt * 64 level-0 nodes
     int32_t nodeCap;                         // capacity of the per-node arrays
     int32_t stackEntries;                    // per-lane traversal stack entries needed (8 bytes each)
-    int32_t stackLds;                        // how many of them live in LDS; the rest in stackSpill
+    int32_t stackLds;                        // size of the LDS ring holding the top of the stack (a power of two)
     uint32_t sceneRootRef;
     uint64_t offRecords;
     int32_t traceWaves;                      // wavefronts of the persistent trace kernels
@@ -185,7 +185,7 @@ struct FrameParams {
     float4* ctx;            // [4 * nodeCap] shading context of each diffuse hit of the current level
     int32_t* ctxNode;       // [nodeCap] node of each diffuse hit
     unsigned char* vis;     // [nodeCap * max(lightCnt,1)] 1 = light visible
-    uint2* stackSpill;      // [traceWaves * (stackEntries - stackLds) * 64] deep stack entries
+    uint2* stackSpill;      // [traceWaves * (stackEntries + RT_MESH_ENTRY_SLOTS) * 64] older stack entries + parked world-space rays
 };
 
 #define RT_MAX_SUBFRAMES 8

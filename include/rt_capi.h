@@ -281,8 +281,10 @@ int rt_timing_read_stages(rt_ctx* ctx, double* totalMs, double* stageMs, int* la
 int rt_set_path_budget(rt_ctx* ctx, int nodesPerPixel);
 
 /* Tuning knob: how many traversal-stack entries per ray are kept in LDS (8 bytes
- * each, 64 rays per wavefront); deeper entries go to a global spill array.
- * Fewer entries = more resident wavefronts per CU.  Results do not depend on it. */
+ * each, 64 rays per wavefront), rounded down to a power of two (at least 2).
+ * They form a ring holding the top of the stack; older entries move to a global
+ * array.  Fewer entries = more resident wavefronts per CU.  Results do not
+ * depend on it. */
 int rt_set_lds_stack(rt_ctx* ctx, int entries);
 
 /* Tuning knob: rt_render splits its tiles into `count` interleaved sub-frames that

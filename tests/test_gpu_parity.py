@@ -88,7 +88,7 @@ def test_knobs_do_not_change_the_frame(gpu_ctx):
     dscene = gpu_ctx.upload(scene)
     try:
         base = gpu_ctx.render_frame(scene, dscene, want_keys=True, want_counters=True)
-        for setter, values, restore in ((gpu_ctx.set_lds_stack, (1, 3, 8, 64), 20), (gpu_ctx.set_subframes, (2, 5, 8), 1),
+        for setter, values, restore in ((gpu_ctx.set_lds_stack, (1, 3, 8, 64), 8), (gpu_ctx.set_subframes, (2, 5, 8), 1),
                                         (gpu_ctx.set_trace_waves, (1, 4, 32), 0)):
             try:
                 for v in values:
@@ -112,7 +112,7 @@ def test_deep_stack_spills_to_global_memory(gpu_ctx, oracle):
     try:
         rgba, keys, cnt = gpu_ctx.render_frame(scene, want_keys=True, want_counters=True)
     finally:
-        gpu_ctx.set_lds_stack(20)
+        gpu_ctx.set_lds_stack(8)
     assert_parity(rgba, keys, ref_rgba, ref_keys)
     assert cnt == ref_cnt
 
