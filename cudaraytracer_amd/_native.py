@@ -110,6 +110,7 @@ C_ABI = {
     "rt_set_lds_stack": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_subframes": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_trace_waves": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_set_tile_order": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 HARNESS = {

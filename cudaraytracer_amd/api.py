@@ -225,6 +225,10 @@ class Context:
     def set_trace_waves(self, waves_per_cu):
         self._check(self.lib.rt_set_trace_waves(self.ctx, waves_per_cu), "rt_set_trace_waves")
 
+    def set_tile_order(self, mode):
+        """0 = row-major, 1 = centre-out (default)."""
+        self._check(self.lib.rt_set_tile_order(self.ctx, mode), "rt_set_tile_order")
+
     def set_subframes(self, count):
         self._check(self.lib.rt_set_subframes(self.ctx, count), "rt_set_subframes")
 

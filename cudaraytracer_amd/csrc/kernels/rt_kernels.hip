@@ -155,9 +155,10 @@ __device__ __forceinline__ V3 invBiasedOrigin(V3 dir, V3 P, V3 n, float bias) {
 
 // ---------------------------------------------------------------------------
 // Level-0 node -> pixel.  Node s of this call is lane (s & 63) of local tile
-// s >> 6; local tile k is frame tile tileFirst + k * tileStride (row-major).
+// s >> 6; local tile k is frame tile tileFirst + k * tileStride (row-major), or tileOrder[k] when the
+// host supplies an order (the same set of tiles, expensive image regions first).
 __device__ __forceinline__ bool slotPixel(const FrameParams& P, int slot, int& x, int& y) {
-    const int tile = P.tileFirst + (slot >> 6) * P.tileStride;
+    const int tile = P.tileOrder ? P.tileOrder[slot >> 6] : P.tileFirst + (slot >> 6) * P.tileStride;
     const int l = slot & 63;
     x = (tile % P.tilesX) * RT_TILE + (l & (RT_TILE - 1));
     y = (tile / P.tilesX) * RT_TILE + (l >> 3);

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/rt_capi.h"
@@ -65,6 +66,11 @@ struct rt_ctx {
     int ldsStack = RT_LDS_STACK_DEFAULT;  // traversal stack entries kept in LDS (deeper ones spill to global memory)
     int subFrames = RT_SUBFRAMES_DEFAULT;  // concurrent sub-frames per rt_render call
     int maxWavesPerCu = 0;                 // 0 = as many as are resident
+    int tileOrderMode = RT_TILE_ORDER_CENTER_OUT;
+    std::vector<int32_t> tileOrderHost;    // per sub-frame lists, back to back
+    void* tileOrderDev = nullptr;
+    size_t tileOrderCap = 0;
+    long long tileOrderKey[6] = {-1, -1, -1, -1, -1, -1};
     hipStream_t subStreams[RT_MAX_SUBFRAMES] = {};
     hipEvent_t subEvents[RT_MAX_SUBFRAMES + 1] = {};
     int wavesPerCu = 0, wavesForLds = -1;
@@ -463,6 +469,7 @@ void rt_destroy(rt_ctx* ctx) {
     for (auto& l : ctx->launches)
         for (hipEvent_t e : l.ev) hipEventDestroy(e);
     freeWorkspace(ctx->ws);
+    if (ctx->tileOrderDev) hipFree(ctx->tileOrderDev);
     for (hipStream_t st : ctx->subStreams)
         if (st) hipStreamDestroy(st);
     for (hipEvent_t e : ctx->subEvents)
@@ -500,6 +507,13 @@ int rt_set_trace_waves(rt_ctx* ctx, int wavesPerCu) {
     if (!ctx) return RT_ERR_INVALID;
     if (wavesPerCu < 0 || wavesPerCu > 32) return fail(ctx, RT_ERR_INVALID, "waves per CU must be in 0..32");
     ctx->maxWavesPerCu = wavesPerCu;
+    return RT_OK;
+}
+
+int rt_set_tile_order(rt_ctx* ctx, int mode) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (mode != RT_TILE_ORDER_ROW_MAJOR && mode != RT_TILE_ORDER_CENTER_OUT) return fail(ctx, RT_ERR_INVALID, "unknown tile order %d", mode);
+    ctx->tileOrderMode = mode;
     return RT_OK;
 }
 
@@ -772,6 +786,45 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
         q.stackSpill = reinterpret_cast<uint2*>(static_cast<unsigned char*>(w.stackSpill) + spillPerSub * i);
         nodeOff += (size_t)q.nodeCap;
         secOff += (size_t)(q.nodeCap - q.slots);
+    }
+
+    // Tile order.  The persistent trace kernels drain their queue front to back; when the image
+    // regions that take longest come first, the last rays in flight are short ones and the
+    // wavefronts run dry together.  Geometry sits around the image centre far more often than in
+    // the corners, so each sub-frame's tiles are handed out centre first.  Which tiles a call
+    // renders does not change, only their order in the queue.
+    if (ctx->tileOrderMode == RT_TILE_ORDER_CENTER_OUT) {
+        const long long key[6] = {p.tilesX, p.tilesY, tileFirst, tileStride, nSubs, (long long)opts->width << 32 | (unsigned)opts->height};
+        if (std::memcmp(key, ctx->tileOrderKey, sizeof key) != 0) {
+            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // an earlier frame may still read the table
+            std::vector<std::pair<long long, int32_t>> all((size_t)myTiles);
+            const long long cx = opts->width, cy = opts->height;  // twice the image centre
+            for (long long k = 0; k < myTiles; ++k) {
+                const int32_t t = (int32_t)(tileFirst + k * tileStride);
+                const long long dx = (long long)(t % p.tilesX) * 2 * RT_TILE + RT_TILE - cx;
+                const long long dy = (long long)(t / p.tilesX) * 2 * RT_TILE + RT_TILE - cy;
+                all[(size_t)k] = {dx * dx + dy * dy, t};
+            }
+            std::sort(all.begin(), all.end());
+            ctx->tileOrderHost.resize((size_t)myTiles);
+            size_t at = 0;
+            for (int i = 0; i < nSubs; ++i)
+                for (long long k = i; k < myTiles; k += nSubs) ctx->tileOrderHost[at++] = all[(size_t)k].second;
+            if ((size_t)myTiles > ctx->tileOrderCap) {
+                if (ctx->tileOrderDev) hipFree(ctx->tileOrderDev);
+                ctx->tileOrderDev = nullptr;
+                ctx->tileOrderCap = 0;
+                RT_HIP(ctx, hipMalloc(&ctx->tileOrderDev, (size_t)myTiles * sizeof(int32_t)));
+                ctx->tileOrderCap = (size_t)myTiles;
+            }
+            RT_HIP(ctx, hipMemcpy(ctx->tileOrderDev, ctx->tileOrderHost.data(), (size_t)myTiles * sizeof(int32_t), hipMemcpyHostToDevice));
+            std::memcpy(ctx->tileOrderKey, key, sizeof key);
+        }
+        size_t at = 0;
+        for (int i = 0; i < nSubs; ++i) {
+            subs[i].tileOrder = static_cast<const int32_t*>(ctx->tileOrderDev) + at;
+            at += (size_t)subs[i].tileCnt;
+        }
     }
 
     if (ctx->launchesUsed == ctx->launches.size()) {

@@ -166,6 +166,7 @@ struct FrameParams {
     // tile shard
     int32_t tilesX, tilesY;
     int32_t tileFirst, tileStride, tileCnt;  // this call renders tiles tileFirst + k*tileStride, k < tileCnt
+    const int32_t* tileOrder;                // optional [tileCnt]: frame tile of local tile k (overrides the arithmetic rule)
     int32_t slots;                           // tileCnt * 64 level-0 nodes
     int32_t nodeCap;                         // capacity of the per-node arrays
     int32_t stackEntries;                    // per-lane traversal stack entries needed (8 bytes each)

@@ -280,6 +280,15 @@ int rt_timing_read_stages(rt_ctx* ctx, double* totalMs, double* stageMs, int* la
  * A frame that needs more reports RT_ERR_LIMIT from rt_sync. */
 int rt_set_path_budget(rt_ctx* ctx, int nodesPerPixel);
 
+/* Order in which a call's 8x8 tiles enter the trace kernels' work queue.  Which tiles
+ * are rendered and every pixel value are the same either way.  CENTER_OUT (default)
+ * starts with the tiles nearest the image centre, where rays usually take longest,
+ * so that the last rays in flight are short ones; the reference has no counterpart
+ * (cudaTracer/Main.cu:46-90 launches one thread per pixel in grid order). */
+#define RT_TILE_ORDER_ROW_MAJOR 0
+#define RT_TILE_ORDER_CENTER_OUT 1
+int rt_set_tile_order(rt_ctx* ctx, int mode);
+
 /* Tuning knob: how many traversal-stack entries per ray are kept in LDS (8 bytes
  * each, 64 rays per wavefront), rounded down to a power of two (at least 2).
  * They form a ring holding the top of the stack; older entries move to a global

@@ -23,6 +23,7 @@ ap.add_argument("--reference-bvh", action="store_true")
 ap.add_argument("--lds-stack", type=int, default=0)
 ap.add_argument("--subframes", type=int, default=0)
 ap.add_argument("--waves", type=int, default=0)
+ap.add_argument("--tile-order", type=int, default=-1)
 a = ap.parse_args()
 
 t = time.time()
@@ -31,6 +32,8 @@ print(f"scene {a.scene} size {a.size}: built in {time.time()-t:.2f}s, depth {sce
 with rt.Context(0) as ctx:
     if a.waves:
         ctx.set_trace_waves(a.waves)
+    if a.tile_order >= 0:
+        ctx.set_tile_order(a.tile_order)
     if a.subframes:
         ctx.set_subframes(a.subframes)
     if a.lds_stack:
