@@ -229,8 +229,12 @@ class Context:
         """0 = row-major, 1 = centre-out (default)."""
         self._check(self.lib.rt_set_tile_order(self.ctx, mode), "rt_set_tile_order")
 
-    def set_subframes(self, count):
-        self._check(self.lib.rt_set_subframes(self.ctx, count), "rt_set_subframes")
+    def set_frames_in_flight(self, frames):
+        """1 = frames run in order on the context's stream; 2..4 = consecutive frames overlap on internal streams."""
+        self._check(self.lib.rt_set_frames_in_flight(self.ctx, frames), "rt_set_frames_in_flight")
+
+    def stream_wait_frame(self, stream_ptr=None, frames_ago=0):
+        self._check(self.lib.rt_stream_wait_frame(self.ctx, stream_ptr, frames_ago), "rt_stream_wait_frame")
 
     def set_lds_stack(self, entries):
         self._check(self.lib.rt_set_lds_stack(self.ctx, entries), "rt_set_lds_stack")

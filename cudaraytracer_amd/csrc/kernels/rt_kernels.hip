@@ -324,6 +324,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     // wave-level statistics (meaningful in lane 0): iterations, node steps and their lanes, triangle phases and their
     // rays, lanes holding a ray
     unsigned long long wSteps = 0, wNodeLanes = 0, wTriLanes = 0, wBusyLanes = 0, wNodeSteps = 0, wTriSteps = 0;
+    unsigned long long wTailSteps = 0, wTailLanes = 0;  // the same after the work queue ran dry
 
     // wave-uniform queue state
     unsigned chunkNext = 0, chunkEnd = 0;
@@ -434,8 +435,13 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
             const int nTri = __popcll(triMask);
             const bool triPhase = nTri != 0 && (nTri >= RT_TRI_LANES || nodeMask == 0ull);
             if (COUNT) {
+                const unsigned nb = (unsigned)__popcll(__ballot(cur != CUR_DONE));
                 wSteps++;
-                wBusyLanes += __popcll(__ballot(cur != CUR_DONE));
+                wBusyLanes += nb;
+                if (exhausted) {
+                    wTailSteps++;
+                    wTailLanes += nb;
+                }
             }
             if (triPhase) {
                 // ================= cooperative triangle phase =================
@@ -638,6 +644,8 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
             atomicAdd(P.counters + b + 3, wTriSteps);
             atomicAdd(P.counters + b + 4, wTriLanes);
             atomicAdd(P.counters + b + 5, wBusyLanes);
+            atomicAdd(P.counters + (ANY ? RT_CNT_STAT_TAIL_SHADOW : RT_CNT_STAT_TAIL_CLOSEST) + 0, wTailSteps);
+            atomicAdd(P.counters + (ANY ? RT_CNT_STAT_TAIL_SHADOW : RT_CNT_STAT_TAIL_CLOSEST) + 1, wTailLanes);
         }
     }
 }
@@ -1030,65 +1038,39 @@ int rtk_trace_waves_per_cu(int stackLds) {
     return w;
 }
 
-// Enqueues the kernel sequence of `nSubs` sub-frames.  With one sub-frame everything runs on
-// `stream`.  With several, sub-frame i runs on subStreams[i] between a fork event recorded on
-// `stream` and a join back into it, so that the draining tail of one sub-frame's persistent
-// trace kernel overlaps with the next sub-frame's work instead of leaving wave slots empty.
-int rtk_render_frame(const FrameParams* subs, int nSubs, int hasSecondary, int count, int cuCount, void* stream, void** subStreams,
-                     void** subEvents, void** stageEvents) {
-    hipStream_t mainStream = reinterpret_cast<hipStream_t>(stream);
+// Enqueues the kernel sequence of one frame on `stream`.
+int rtk_render_frame(const FrameParams* frame, int hasSecondary, int count, int cuCount, void* stream, void** stageEvents) {
+    const FrameParams& p = *frame;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t* ev = reinterpret_cast<hipEvent_t*>(stageEvents);
-    hipEvent_t* fj = reinterpret_cast<hipEvent_t*>(subEvents);
-    const bool split = nSubs > 1;
-    const int lastLevel = hasSecondary ? subs[0].opts.maxDepth : 0;
+    const int lastLevel = hasSecondary ? p.opts.maxDepth : 0;
     const dim3 wide(cuCount * 8), block(256);
-    auto streamOf = [&](int i) { return split ? reinterpret_cast<hipStream_t>(subStreams[i]) : mainStream; };
-    if (ev) (void)hipEventRecord(ev[0], mainStream);
-    if (split) {
-        (void)hipEventRecord(fj[0], mainStream);
-        for (int i = 0; i < nSubs; ++i) (void)hipStreamWaitEvent(streamOf(i), fj[0], 0);
-        if (ev)
-            for (int k = 1; k < 4; ++k) (void)hipEventRecord(ev[k], mainStream);  // no per-stage split in this mode
-    }
-    for (int i = 0; i < nSubs; ++i) {
-        hipError_t e = hipMemsetAsync(subs[i].ctl, 0, CTL_WORDS * sizeof(uint32_t), streamOf(i));
-        if (e != hipSuccess) return (int)e;
-    }
+    if (ev) (void)hipEventRecord(ev[0], s);
+    hipError_t e = hipMemsetAsync(p.ctl, 0, CTL_WORDS * sizeof(uint32_t), s);
+    if (e != hipSuccess) return (int)e;
     for (int level = 0; level <= lastLevel; ++level) {
-        for (int i = 0; i < nSubs; ++i) {
-            const FrameParams& p = subs[i];
-            hipStream_t s = streamOf(i);
-            hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(64), 0, s, p, level);
+        hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(64), 0, s, p, level);
+        if (count)
+            launchTrace<false, true>(p, level, cuCount, s);
+        else
+            launchTrace<false, false>(p, level, cuCount, s);
+        if (ev && level == 0) (void)hipEventRecord(ev[1], s);
+        if (count)
+            hipLaunchKernelGGL((shadeKernel<true>), wide, block, 0, s, p, level);
+        else
+            hipLaunchKernelGGL((shadeKernel<false>), wide, block, 0, s, p, level);
+        if (ev && level == 0) (void)hipEventRecord(ev[2], s);
+        if (p.lightCnt > 0) {
             if (count)
-                launchTrace<false, true>(p, level, cuCount, s);
+                launchTrace<true, true>(p, level, cuCount, s);
             else
-                launchTrace<false, false>(p, level, cuCount, s);
-            if (ev && !split && level == 0) (void)hipEventRecord(ev[1], s);
-            if (count)
-                hipLaunchKernelGGL((shadeKernel<true>), wide, block, 0, s, p, level);
-            else
-                hipLaunchKernelGGL((shadeKernel<false>), wide, block, 0, s, p, level);
-            if (ev && !split && level == 0) (void)hipEventRecord(ev[2], s);
-            if (p.lightCnt > 0) {
-                if (count)
-                    launchTrace<true, true>(p, level, cuCount, s);
-                else
-                    launchTrace<true, false>(p, level, cuCount, s);
-            }
-            if (ev && !split && level == 0) (void)hipEventRecord(ev[3], s);
-            hipLaunchKernelGGL(accumKernel, wide, block, 0, s, p);
+                launchTrace<true, false>(p, level, cuCount, s);
         }
+        if (ev && level == 0) (void)hipEventRecord(ev[3], s);
+        hipLaunchKernelGGL(accumKernel, wide, block, 0, s, p);
     }
-    for (int i = 0; i < nSubs; ++i) {
-        const FrameParams& p = subs[i];
-        hipStream_t s = streamOf(i);
-        for (int level = lastLevel - 1; level >= 0; --level) hipLaunchKernelGGL(resolveKernel, wide, block, 0, s, p, level);
-        hipLaunchKernelGGL(finalizeKernel, wide, block, 0, s, p);
-        if (split) {
-            (void)hipEventRecord(fj[1 + i], s);
-            (void)hipStreamWaitEvent(mainStream, fj[1 + i], 0);
-        }
-    }
-    if (ev) (void)hipEventRecord(ev[4], mainStream);
+    for (int level = lastLevel - 1; level >= 0; --level) hipLaunchKernelGGL(resolveKernel, wide, block, 0, s, p, level);
+    hipLaunchKernelGGL(finalizeKernel, wide, block, 0, s, p);
+    if (ev) (void)hipEventRecord(ev[4], s);
     return (int)hipGetLastError();
 }

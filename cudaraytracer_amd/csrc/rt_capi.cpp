@@ -17,9 +17,6 @@
 #include "../../include/rt_capi.h"
 #include "rt_device_format.h"
 
-#ifndef RT_SUBFRAMES_DEFAULT
-#define RT_SUBFRAMES_DEFAULT 1
-#endif
 #ifndef RT_LDS_STACK_DEFAULT
 #define RT_LDS_STACK_DEFAULT 8
 #endif
@@ -56,23 +53,32 @@ struct Workspace {
 
 }  // namespace
 
+// One frame in flight: its own stream and workspace, so that consecutive frames can overlap.
+struct FrameSlot {
+    Workspace ws;
+    hipStream_t stream = nullptr;  // created on first use; slot 0 of a strictly ordered context uses the context's stream
+    hipEvent_t ready = nullptr;    // recorded on the context's stream when the frame is issued
+    hipEvent_t done = nullptr;     // recorded behind the frame's last kernel
+    hipStream_t lastStream = nullptr;  // stream the slot's latest frame ran on
+    bool issued = false;
+};
+
 struct rt_ctx {
     int device = 0;
     int cuCount = 0;
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
-    Workspace ws;
+    FrameSlot slots[RT_MAX_FRAMES_IN_FLIGHT];
+    int framesInFlight = 1;
+    unsigned long long frameCounter = 0;  // frames issued so far
     int pathBudget = 3;  // node arrays hold pathBudget x pixels when the scene has mirror / glass materials
-    int ldsStack = RT_LDS_STACK_DEFAULT;  // traversal stack entries kept in LDS (deeper ones spill to global memory)
-    int subFrames = RT_SUBFRAMES_DEFAULT;  // concurrent sub-frames per rt_render call
-    int maxWavesPerCu = 0;                 // 0 = as many as are resident
+    int ldsStack = RT_LDS_STACK_DEFAULT;  // traversal stack entries kept in LDS (older ones move to global memory)
+    int maxWavesPerCu = 0;                // 0 = as many as are resident
     int tileOrderMode = RT_TILE_ORDER_CENTER_OUT;
-    std::vector<int32_t> tileOrderHost;    // per sub-frame lists, back to back
+    std::vector<int32_t> tileOrderHost;
     void* tileOrderDev = nullptr;
     size_t tileOrderCap = 0;
     long long tileOrderKey[6] = {-1, -1, -1, -1, -1, -1};
-    hipStream_t subStreams[RT_MAX_SUBFRAMES] = {};
-    hipEvent_t subEvents[RT_MAX_SUBFRAMES + 1] = {};
     int wavesPerCu = 0, wavesForLds = -1;
     std::string error;
     std::vector<TimedLaunch> launches;  // events of launches since the last reset
@@ -371,11 +377,10 @@ void freeWorkspace(Workspace& w) {
 }
 
 // Makes the workspace hold `nodeCap` path nodes (`slots` of them level 0) and `lights` lights.
-int ensureWorkspace(rt_ctx* ctx, int nodeCap, int slots, int lights, size_t spillBytes) {
-    Workspace& w = ctx->ws;
+int ensureWorkspace(rt_ctx* ctx, Workspace& w, hipStream_t stream, int nodeCap, int slots, int lights, size_t spillBytes) {
     const int secCap = nodeCap - slots;
     if (spillBytes > w.spillBytes) {
-        RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        RT_HIP(ctx, hipStreamSynchronize(stream));
         if (w.stackSpill) hipFree(w.stackSpill);
         w.stackSpill = nullptr;
         w.spillBytes = 0;
@@ -383,7 +388,7 @@ int ensureWorkspace(rt_ctx* ctx, int nodeCap, int slots, int lights, size_t spil
         w.spillBytes = spillBytes;
     }
     if (w.ctl && nodeCap <= w.nodeCap && lights <= w.lightCap && secCap <= w.secCap) return RT_OK;
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // frames in flight still use the old arrays
+    RT_HIP(ctx, hipStreamSynchronize(stream));  // the slot's previous frame may still use the old arrays
     const int nc = std::max(nodeCap, w.nodeCap), lc = std::max(std::max(lights, 1), w.lightCap), sc = std::max(secCap, w.secCap);
     {
         void* keepSpill = w.stackSpill;
@@ -394,8 +399,8 @@ int ensureWorkspace(rt_ctx* ctx, int nodeCap, int slots, int lights, size_t spil
         w.spillBytes = keepBytes;
     }
     const size_t n = (size_t)nc;
-    RT_HIP(ctx, hipMalloc(&w.ctl, RT_MAX_SUBFRAMES * CTL_WORDS * sizeof(uint32_t)));
-    RT_HIP(ctx, hipMemset(w.ctl, 0, RT_MAX_SUBFRAMES * CTL_WORDS * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMalloc(&w.ctl, CTL_WORDS * sizeof(uint32_t)));
+    RT_HIP(ctx, hipMemset(w.ctl, 0, CTL_WORDS * sizeof(uint32_t)));
     RT_HIP(ctx, hipMalloc(&w.hit, n * 16));
     RT_HIP(ctx, hipMalloc(&w.hitTri, n * 4));
     RT_HIP(ctx, hipMalloc(&w.color, n * 16));
@@ -409,6 +414,14 @@ int ensureWorkspace(rt_ctx* ctx, int nodeCap, int slots, int lights, size_t spil
     w.nodeCap = nc;
     w.lightCap = lc;
     w.secCap = sc;
+    return RT_OK;
+}
+
+// Waits (on the host) for every frame issued so far.
+int syncFrames(rt_ctx* ctx) {
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (FrameSlot& sl : ctx->slots)
+        if (sl.issued && sl.lastStream) RT_HIP(ctx, hipStreamSynchronize(sl.lastStream));
     return RT_OK;
 }
 
@@ -451,14 +464,6 @@ rt_ctx* rt_create(int device) {
     }
     ctx->cuCount = prop.multiProcessorCount;
     ctx->stream = ctx->ownStream;
-    bool ok = true;
-    for (int i = 0; i < RT_MAX_SUBFRAMES; ++i) ok = ok && hipStreamCreateWithFlags(&ctx->subStreams[i], hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i <= RT_MAX_SUBFRAMES; ++i) ok = ok && hipEventCreateWithFlags(&ctx->subEvents[i], hipEventDisableTiming) == hipSuccess;
-    if (!ok) {
-        fail(nullptr, RT_ERR_DEVICE, "cannot create streams / events on device %d", device);
-        rt_destroy(ctx);
-        return nullptr;
-    }
     return ctx;
 }
 
@@ -468,12 +473,14 @@ void rt_destroy(rt_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     for (auto& l : ctx->launches)
         for (hipEvent_t e : l.ev) hipEventDestroy(e);
-    freeWorkspace(ctx->ws);
+    for (FrameSlot& sl : ctx->slots) {
+        if (sl.lastStream) hipStreamSynchronize(sl.lastStream);
+        freeWorkspace(sl.ws);
+        if (sl.stream) hipStreamDestroy(sl.stream);
+        if (sl.ready) hipEventDestroy(sl.ready);
+        if (sl.done) hipEventDestroy(sl.done);
+    }
     if (ctx->tileOrderDev) hipFree(ctx->tileOrderDev);
-    for (hipStream_t st : ctx->subStreams)
-        if (st) hipStreamDestroy(st);
-    for (hipEvent_t e : ctx->subEvents)
-        if (e) hipEventDestroy(e);
     hipStreamDestroy(ctx->ownStream);
     delete ctx;
 }
@@ -489,17 +496,38 @@ int rt_set_stream(rt_ctx* ctx, void* hipStream) {
 int rt_sync(rt_ctx* ctx) {
     if (!ctx) return RT_ERR_INVALID;
     if (int r = bind(ctx)) return r;
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->ws.ctl) {
-        uint32_t blocks[RT_MAX_SUBFRAMES * CTL_WORDS];
-        RT_HIP(ctx, hipMemcpy(blocks, ctx->ws.ctl, sizeof blocks, hipMemcpyDeviceToHost));
-        uint32_t overflow = 0;
-        for (int i = 0; i < RT_MAX_SUBFRAMES; ++i) overflow |= blocks[i * CTL_WORDS + CTL_OVERFLOW];
-        if (overflow)
-            return fail(ctx, RT_ERR_LIMIT,
-                        "reflection / refraction rays exceeded the path budget of %d x pixels; raise it with rt_set_path_budget",
-                        ctx->pathBudget);
+    if (int r = syncFrames(ctx)) return r;
+    uint32_t overflow = 0;
+    for (FrameSlot& sl : ctx->slots) {
+        if (!sl.ws.ctl) continue;
+        uint32_t block[CTL_WORDS];
+        RT_HIP(ctx, hipMemcpy(block, sl.ws.ctl, sizeof block, hipMemcpyDeviceToHost));
+        overflow |= block[CTL_OVERFLOW];
     }
+    if (overflow)
+        return fail(ctx, RT_ERR_LIMIT, "reflection / refraction rays exceeded the path budget of %d x pixels; raise it with rt_set_path_budget",
+                    ctx->pathBudget);
+    return RT_OK;
+}
+
+int rt_set_frames_in_flight(rt_ctx* ctx, int frames) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (frames < 1 || frames > RT_MAX_FRAMES_IN_FLIGHT) return fail(ctx, RT_ERR_INVALID, "frames in flight must be in 1..%d", RT_MAX_FRAMES_IN_FLIGHT);
+    if (int r = bind(ctx)) return r;
+    if (int r = syncFrames(ctx)) return r;
+    ctx->framesInFlight = frames;
+    return RT_OK;
+}
+
+int rt_stream_wait_frame(rt_ctx* ctx, void* hipStream, int framesAgo) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (framesAgo < 0 || framesAgo >= RT_MAX_FRAMES_IN_FLIGHT) return fail(ctx, RT_ERR_INVALID, "framesAgo must be in 0..%d", RT_MAX_FRAMES_IN_FLIGHT - 1);
+    if ((unsigned long long)framesAgo >= ctx->frameCounter) return RT_OK;  // nothing issued that far back
+    if (framesAgo >= ctx->framesInFlight) return RT_OK;                      // its slot has been reused since: it is complete
+    if (int r = bind(ctx)) return r;
+    const FrameSlot& sl = ctx->slots[(ctx->frameCounter - 1 - (unsigned long long)framesAgo) % (unsigned long long)ctx->framesInFlight];
+    if (!sl.issued || !sl.done) return RT_OK;
+    RT_HIP(ctx, hipStreamWaitEvent(hipStream ? reinterpret_cast<hipStream_t>(hipStream) : ctx->stream, sl.done, 0));
     return RT_OK;
 }
 
@@ -514,13 +542,6 @@ int rt_set_tile_order(rt_ctx* ctx, int mode) {
     if (!ctx) return RT_ERR_INVALID;
     if (mode != RT_TILE_ORDER_ROW_MAJOR && mode != RT_TILE_ORDER_CENTER_OUT) return fail(ctx, RT_ERR_INVALID, "unknown tile order %d", mode);
     ctx->tileOrderMode = mode;
-    return RT_OK;
-}
-
-int rt_set_subframes(rt_ctx* ctx, int count) {
-    if (!ctx) return RT_ERR_INVALID;
-    if (count < 1 || count > RT_MAX_SUBFRAMES) return fail(ctx, RT_ERR_INVALID, "sub-frame count must be in 1..%d", RT_MAX_SUBFRAMES);
-    ctx->subFrames = count;
     return RT_OK;
 }
 
@@ -749,54 +770,50 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     }
     p.traceWaves = (ctx->maxWavesPerCu > 0 ? std::min(ctx->wavesPerCu, ctx->maxWavesPerCu) : ctx->wavesPerCu) * ctx->cuCount;
 
-    // Sub-frames: local tile k of this call goes to sub-frame k % nSubs, so every sub-frame
-    // is a regular sample of the same image region and costs about the same.
-    int nSubs = (int)std::min<long long>(std::max(ctx->subFrames, 1), myTiles);
-    FrameParams subs[RT_MAX_SUBFRAMES];
-    long long totalNodes = 0, totalSec = 0;
-    for (int i = 0; i < nSubs; ++i) {
-        FrameParams& q = subs[i];
-        q = p;
-        q.tileFirst = tileFirst + i * tileStride;
-        q.tileStride = tileStride * nSubs;
-        q.tileCnt = (int)((myTiles - i + nSubs - 1) / nSubs);
-        q.slots = q.tileCnt * RT_TILE * RT_TILE;
-        q.nodeCap = q.slots * budget;
-        totalNodes += q.nodeCap;
-        totalSec += q.nodeCap - q.slots;
+    p.tileFirst = tileFirst;
+    p.tileStride = tileStride;
+    p.tileCnt = (int)myTiles;
+    p.slots = p.tileCnt * RT_TILE * RT_TILE;
+    p.nodeCap = p.slots * budget;
+
+    // The frame's slot: with one frame in flight it runs on the context's stream, in order.  With
+    // several, it runs on the slot's own stream behind everything enqueued on the context's
+    // stream so far (and behind the slot's previous frame), and overlaps with the other slots.
+    FrameSlot& sl = ctx->slots[ctx->frameCounter % (unsigned long long)ctx->framesInFlight];
+    const bool forked = ctx->framesInFlight > 1;
+    if (!sl.done) RT_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (forked && !sl.stream) {
+        RT_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+        RT_HIP(ctx, hipEventCreateWithFlags(&sl.ready, hipEventDisableTiming));
     }
-    const size_t spillPerSub = (size_t)p.traceWaves * (size_t)(p.stackEntries + RT_MESH_ENTRY_SLOTS) * 64 * 8;
-    if (int r = ensureWorkspace(ctx, (int)totalNodes, (int)(totalNodes - totalSec), hd.lightCnt, std::max<size_t>(spillPerSub * nSubs, 256))) return r;
-    const Workspace& w = ctx->ws;
-    const size_t lc = (size_t)std::max(hd.lightCnt, 1);
-    size_t nodeOff = 0, secOff = 0;
-    for (int i = 0; i < nSubs; ++i) {
-        FrameParams& q = subs[i];
-        q.ctl = static_cast<uint32_t*>(w.ctl) + (size_t)i * CTL_WORDS;
-        q.hit = static_cast<float4*>(w.hit) + nodeOff;
-        q.hitTri = static_cast<int32_t*>(w.hitTri) + nodeOff;
-        q.color = static_cast<float4*>(w.color) + nodeOff;
-        q.secRay = static_cast<float4*>(w.secRay) + 2 * secOff;
-        q.child = static_cast<int32_t*>(w.child) + nodeOff;
-        q.kr = static_cast<float*>(w.kr) + nodeOff;
-        q.kind = static_cast<int32_t*>(w.kind) + nodeOff;
-        q.ctx = static_cast<float4*>(w.ctx) + 4 * nodeOff;
-        q.ctxNode = static_cast<int32_t*>(w.ctxNode) + nodeOff;
-        q.vis = static_cast<unsigned char*>(w.vis) + nodeOff * lc;
-        q.stackSpill = reinterpret_cast<uint2*>(static_cast<unsigned char*>(w.stackSpill) + spillPerSub * i);
-        nodeOff += (size_t)q.nodeCap;
-        secOff += (size_t)(q.nodeCap - q.slots);
-    }
+    hipStream_t exec = forked ? sl.stream : ctx->stream;
+    if (sl.issued && sl.lastStream && sl.lastStream != exec) RT_HIP(ctx, hipStreamWaitEvent(exec, sl.done, 0));
+
+    const size_t spillBytes = (size_t)p.traceWaves * (size_t)(p.stackEntries + RT_MESH_ENTRY_SLOTS) * 64 * 8;
+    if (int r = ensureWorkspace(ctx, sl.ws, sl.lastStream ? sl.lastStream : exec, p.nodeCap, p.slots, hd.lightCnt, std::max<size_t>(spillBytes, 256))) return r;
+    const Workspace& w = sl.ws;
+    p.ctl = static_cast<uint32_t*>(w.ctl);
+    p.hit = static_cast<float4*>(w.hit);
+    p.hitTri = static_cast<int32_t*>(w.hitTri);
+    p.color = static_cast<float4*>(w.color);
+    p.secRay = static_cast<float4*>(w.secRay);
+    p.child = static_cast<int32_t*>(w.child);
+    p.kr = static_cast<float*>(w.kr);
+    p.kind = static_cast<int32_t*>(w.kind);
+    p.ctx = static_cast<float4*>(w.ctx);
+    p.ctxNode = static_cast<int32_t*>(w.ctxNode);
+    p.vis = static_cast<unsigned char*>(w.vis);
+    p.stackSpill = static_cast<uint2*>(w.stackSpill);
 
     // Tile order.  The persistent trace kernels drain their queue front to back; when the image
     // regions that take longest come first, the last rays in flight are short ones and the
     // wavefronts run dry together.  Geometry sits around the image centre far more often than in
-    // the corners, so each sub-frame's tiles are handed out centre first.  Which tiles a call
-    // renders does not change, only their order in the queue.
+    // the corners, so the tiles are handed out centre first.  Which tiles a call renders does not
+    // change, only their order in the queue.
     if (ctx->tileOrderMode == RT_TILE_ORDER_CENTER_OUT) {
-        const long long key[6] = {p.tilesX, p.tilesY, tileFirst, tileStride, nSubs, (long long)opts->width << 32 | (unsigned)opts->height};
+        const long long key[6] = {p.tilesX, p.tilesY, tileFirst, tileStride, opts->width, opts->height};
         if (std::memcmp(key, ctx->tileOrderKey, sizeof key) != 0) {
-            RT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // an earlier frame may still read the table
+            if (int r = syncFrames(ctx)) return r;  // earlier frames may still read the table
             std::vector<std::pair<long long, int32_t>> all((size_t)myTiles);
             const long long cx = opts->width, cy = opts->height;  // twice the image centre
             for (long long k = 0; k < myTiles; ++k) {
@@ -807,9 +824,7 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
             }
             std::sort(all.begin(), all.end());
             ctx->tileOrderHost.resize((size_t)myTiles);
-            size_t at = 0;
-            for (int i = 0; i < nSubs; ++i)
-                for (long long k = i; k < myTiles; k += nSubs) ctx->tileOrderHost[at++] = all[(size_t)k].second;
+            for (long long k = 0; k < myTiles; ++k) ctx->tileOrderHost[(size_t)k] = all[(size_t)k].second;
             if ((size_t)myTiles > ctx->tileOrderCap) {
                 if (ctx->tileOrderDev) hipFree(ctx->tileOrderDev);
                 ctx->tileOrderDev = nullptr;
@@ -820,11 +835,7 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
             RT_HIP(ctx, hipMemcpy(ctx->tileOrderDev, ctx->tileOrderHost.data(), (size_t)myTiles * sizeof(int32_t), hipMemcpyHostToDevice));
             std::memcpy(ctx->tileOrderKey, key, sizeof key);
         }
-        size_t at = 0;
-        for (int i = 0; i < nSubs; ++i) {
-            subs[i].tileOrder = static_cast<const int32_t*>(ctx->tileOrderDev) + at;
-            at += (size_t)subs[i].tileCnt;
-        }
+        p.tileOrder = static_cast<const int32_t*>(ctx->tileOrderDev);
     }
 
     if (ctx->launchesUsed == ctx->launches.size()) {
@@ -834,10 +845,16 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
         ctx->launches.push_back(l);
     }
     TimedLaunch& l = ctx->launches[ctx->launchesUsed];
-    hipError_t e = (hipError_t)rtk_render_frame(subs, nSubs, secondary, p.counters ? 1 : 0, ctx->cuCount, ctx->stream,
-                                                reinterpret_cast<void**>(ctx->subStreams), reinterpret_cast<void**>(ctx->subEvents),
-                                                reinterpret_cast<void**>(l.ev));
+    if (forked) {
+        RT_HIP(ctx, hipEventRecord(sl.ready, ctx->stream));
+        RT_HIP(ctx, hipStreamWaitEvent(exec, sl.ready, 0));
+    }
+    hipError_t e = (hipError_t)rtk_render_frame(&p, secondary, p.counters ? 1 : 0, ctx->cuCount, exec, reinterpret_cast<void**>(l.ev));
     if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
+    RT_HIP(ctx, hipEventRecord(sl.done, exec));
+    sl.issued = true;
+    sl.lastStream = exec;
+    ctx->frameCounter++;
     ctx->launchesUsed++;
     return RT_OK;
 }

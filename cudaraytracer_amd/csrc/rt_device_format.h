@@ -189,17 +189,12 @@ struct FrameParams {
     uint2* stackSpill;      // [traceWaves * (stackEntries + RT_MESH_ENTRY_SLOTS) * 64] older stack entries + parked world-space rays
 };
 
-#define RT_MAX_SUBFRAMES 8
+#define RT_MAX_FRAMES_IN_FLIGHT 4
 
-// Enqueues all kernels of one frame (no host synchronisation).  The frame is given as nSubs
-// sub-frames (disjoint tile sets with their own workspace slices and control blocks); with
-// nSubs > 1 they run concurrently on subStreams[] (subEvents = hipEvent_t[1 + nSubs] for the
-// fork and the joins) and are joined back into `stream`.
+// Enqueues all kernels of one frame on `stream` (no host synchronisation).
 // `stageEvents`: optional hipEvent_t[5] recorded at frame start, after the level-0 closest-hit
-// trace, after shading, after the shadow trace (these three only split the time when nSubs == 1),
-// at frame end.  Returns a hipError_t value.
-int rtk_render_frame(const FrameParams* subs, int nSubs, int hasSecondary, int count, int cuCount, void* stream, void** subStreams,
-                     void** subEvents, void** stageEvents);
+// trace, after shading, after the shadow trace, at frame end.  Returns a hipError_t value.
+int rtk_render_frame(const FrameParams* frame, int hasSecondary, int count, int cuCount, void* stream, void** stageEvents);
 // Resident wavefronts per CU of the trace kernels for a given LDS stack size.
 int rtk_trace_waves_per_cu(int stackLds);
 

@@ -191,9 +191,12 @@ enum {
     RT_CNT_SHADOW_SPHERE = 11,
     RT_CNT_SHADOW_MESH_ENTRY = 12,
     /* wave-step statistics of the trace kernels (diagnostics; six words each):
-     * steps, node steps, lanes in node steps, triangle steps, lanes in triangle steps, lanes holding a ray */
+     * iterations, node steps, lanes in node steps, triangle phases, rays in triangle phases, lanes holding a ray */
     RT_CNT_STAT_CLOSEST = 16,
     RT_CNT_STAT_SHADOW = 22,
+    /* iterations after the work queue ran dry, lanes holding a ray in them (two words each) */
+    RT_CNT_STAT_TAIL_CLOSEST = 28,
+    RT_CNT_STAT_TAIL_SHADOW = 30,
     RT_COUNTER_CNT = 32
 };
 typedef struct RtFrameAux {
@@ -296,12 +299,21 @@ int rt_set_tile_order(rt_ctx* ctx, int mode);
  * depend on it. */
 int rt_set_lds_stack(rt_ctx* ctx, int entries);
 
-/* Tuning knob: rt_render splits its tiles into `count` interleaved sub-frames that
- * run concurrently on internal streams (joined before the call's work is complete
- * on the context's stream), so that the draining tail of one persistent trace
- * kernel overlaps with other work.  1 = plain single-stream order.  Results do
- * not depend on it. */
-int rt_set_subframes(rt_ctx* ctx, int count);
+/* Frames in flight (1..4, default 1).  With 1, rt_render enqueues the frame on the
+ * context's stream, in order, as the reference's cudamain does on the default
+ * stream (cudaTracer/Main.cu:92-119).  With more, consecutive rt_render calls run
+ * on internal streams and overlap: each frame starts behind everything enqueued
+ * on the context's stream at the time of its call, but the context's stream does
+ * NOT wait for it.  Frames that overlap must be given different surfaces and aux
+ * buffers.  rt_sync waits for all of them; rt_stream_wait_frame orders a stream
+ * behind one of them.  Overlap fills the wave slots that the persistent trace
+ * kernels leave empty while their last rays finish.  The reference has no
+ * counterpart (it synchronises the device after every frame). */
+int rt_set_frames_in_flight(rt_ctx* ctx, int frames);
+
+/* Makes `hipStream` (NULL = the context's stream) wait, on the device, for the
+ * frame issued `framesAgo` rt_render calls ago (0 = the latest). */
+int rt_stream_wait_frame(rt_ctx* ctx, void* hipStream, int framesAgo);
 
 /* Tuning knob: upper bound on persistent trace wavefronts per CU (0 = as many as
  * the hardware keeps resident).  Results do not depend on it. */

@@ -88,7 +88,7 @@ def test_knobs_do_not_change_the_frame(gpu_ctx):
     dscene = gpu_ctx.upload(scene)
     try:
         base = gpu_ctx.render_frame(scene, dscene, want_keys=True, want_counters=True)
-        for setter, values, restore in ((gpu_ctx.set_lds_stack, (1, 3, 8, 64), 8), (gpu_ctx.set_subframes, (2, 5, 8), 1),
+        for setter, values, restore in ((gpu_ctx.set_lds_stack, (1, 3, 8, 64), 8), (gpu_ctx.set_frames_in_flight, (2, 4), 1), (gpu_ctx.set_tile_order, (0, 1), 1),
                                         (gpu_ctx.set_trace_waves, (1, 4, 32), 0)):
             try:
                 for v in values:
@@ -145,6 +145,36 @@ def test_tile_shards_compose_the_frame(gpu_ctx, world):
         gpu_ctx.free(keys)
         gpu_ctx.free(cnt)
         gpu_ctx.free_scene(dscene)
+
+
+def test_frames_in_flight_overlap_without_mixing(gpu_ctx):
+    """Three frames in flight, six frames of two different scenes into six surfaces: each equals its in-order render."""
+    w, h = 160, 96
+    scenes = [rt.HostScene("mixed", w, h, 0, 3, 3), rt.HostScene("soup", w, h, 30000, 2, 0, tight_bvh=True)]
+    dscenes = [gpu_ctx.upload(s) for s in scenes]
+    expect = [gpu_ctx.render_frame(s, d, want_keys=True) for s, d in zip(scenes, dscenes)]
+    surfs = [gpu_ctx.surface(w, h) for _ in range(6)]
+    keys = [gpu_ctx.alloc(w * h * 16) for _ in range(6)]
+    gpu_ctx.set_frames_in_flight(3)
+    try:
+        for i in range(6):
+            gpu_ctx.render(dscenes[i % 2], scenes[i % 2].opts, scenes[i % 2].camera, surfs[i][0], surfs[i][1], keys[i])
+        # a stream can be ordered behind one frame without a host wait
+        gpu_ctx.stream_wait_frame(None, 0)
+        gpu_ctx.stream_wait_frame(None, 2)
+        gpu_ctx.sync()
+        for i in range(6):
+            rgba = gpu_ctx.download_surface(surfs[i][0], surfs[i][1], w, h)
+            k = gpu_ctx.download(keys[i], (h, w, 4), np.int32)
+            assert np.array_equal(k, expect[i % 2][1]), i
+            assert np.array_equal(rgba, expect[i % 2][0], equal_nan=True), i
+    finally:
+        gpu_ctx.set_frames_in_flight(1)
+        for sf, k in zip(surfs, keys):
+            gpu_ctx.free(sf[0])
+            gpu_ctx.free(k)
+        for d in dscenes:
+            gpu_ctx.free_scene(d)
 
 
 def test_adopted_blob_renders_like_an_uploaded_scene(gpu_ctx):

@@ -21,7 +21,7 @@ ap.add_argument("--max-depth", type=int, default=0)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--reference-bvh", action="store_true")
 ap.add_argument("--lds-stack", type=int, default=0)
-ap.add_argument("--subframes", type=int, default=0)
+ap.add_argument("--frames-in-flight", type=int, default=0)
 ap.add_argument("--waves", type=int, default=0)
 ap.add_argument("--tile-order", type=int, default=-1)
 a = ap.parse_args()
@@ -34,8 +34,8 @@ with rt.Context(0) as ctx:
         ctx.set_trace_waves(a.waves)
     if a.tile_order >= 0:
         ctx.set_tile_order(a.tile_order)
-    if a.subframes:
-        ctx.set_subframes(a.subframes)
+    if a.frames_in_flight:
+        ctx.set_frames_in_flight(a.frames_in_flight)
     if a.lds_stack:
         ctx.set_lds_stack(a.lds_stack)
     ds = ctx.upload(scene)
@@ -49,15 +49,22 @@ with rt.Context(0) as ctx:
     for name, b in (("closest", 16), ("shadow", 22)):
         st = [int(v) for v in raw[b:b + 6]]
         if st[0]:
+            tl = [int(v) for v in raw[28 + (0 if name == "closest" else 2):30 + (0 if name == "closest" else 2)]]
+            print(f"  {name}: tail {100.0*tl[0]/st[0]:.1f}% of the wave-steps with {tl[1]/max(tl[0],1):.1f} lanes; before it {(st[5]-tl[1])/max(st[0]-tl[0],1):.1f} lanes")
             print(f"  {name}: wave-steps {st[0]}  node-steps {st[1]} (avg lanes {st[2]/max(st[1],1):.1f})  tri-steps {st[3]} (avg lanes {st[4]/max(st[3],1):.1f})  avg lanes with a ray {st[5]/st[0]:.1f}")
     rays = c["primary"] + c["shadow"] + c["secondary"]
-    for _ in range(2):
-        ctx.render(ds, scene.opts, scene.camera, surf, pitch)
+    nf = max(a.frames_in_flight, 1)
+    surfs = [surf] + [ctx.surface(a.width, a.height)[0] for _ in range(nf - 1)]
+    for i in range(2 * nf):
+        ctx.render(ds, scene.opts, scene.camera, surfs[i % nf], pitch)
     ctx.sync()
     ctx.timing_reset()
-    for _ in range(a.steps):
-        ctx.render(ds, scene.opts, scene.camera, surf, pitch)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ctx.render(ds, scene.opts, scene.camera, surfs[i % nf], pitch)
     ctx.sync()
+    wall = (time.perf_counter() - t0) / a.steps * 1e3
     total, st, n = ctx.timing_read_stages()
     print(f"rays/frame {rays} (primary {c['primary']} shadow {c['shadow']} secondary {c['secondary']}), node/ray {c['node']/rays:.1f} tri/ray {c['tri']/rays:.1f}")
-    print(f"frame {total/n:.3f} ms  | primary-trace {st[0]/n:.3f}  shade {st[1]/n:.3f}  shadow-trace {st[2]/n:.3f}  rest {st[3]/n:.3f}  | {rays/(total/n)/1e3:.1f} Mrays/s", flush=True)
+    print(f"frame {total/n:.3f} ms  | primary-trace {st[0]/n:.3f}  shade {st[1]/n:.3f}  shadow-trace {st[2]/n:.3f}  rest {st[3]/n:.3f}  | "
+          f"wall {wall:.3f} ms/frame = {rays/wall/1e3:.1f} Mrays/s", flush=True)
