@@ -68,3 +68,7 @@ with rt.Context(0) as ctx:
     print(f"rays/frame {rays} (primary {c['primary']} shadow {c['shadow']} secondary {c['secondary']}), node/ray {c['node']/rays:.1f} tri/ray {c['tri']/rays:.1f}")
     print(f"frame {total/n:.3f} ms  | primary-trace {st[0]/n:.3f}  shade {st[1]/n:.3f}  shadow-trace {st[2]/n:.3f}  rest {st[3]/n:.3f}  | "
           f"wall {wall:.3f} ms/frame = {rays/wall/1e3:.1f} Mrays/s", flush=True)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ctx.download_surface(surfs[0], pitch, a.width, a.height)
+    print(f"surface download (pageable host memory): {(time.perf_counter()-t0)/5*1e3:.3f} ms per frame")
