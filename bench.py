@@ -51,7 +51,9 @@ def parse():
     ap.add_argument("--reference-bvh", action="store_true", help="build BVHs with the reference's FLT_MIN-clamped boxes")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--frames-in-flight", type=int, default=2, help="consecutive frames that may overlap on the GPU (1 = strictly in order)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="consecutive frames that may overlap on a GPU (1 = strictly in order; default 2, or 4 with several GPUs, "
+                         "where each GPU's share of a frame is too small to fill it)")
     return ap.parse_args()
 
 
@@ -96,17 +98,24 @@ def main():
     import torch
 
     multi = world > 1
+    # Rehearsal mode for a box with ONE GPU: every rank uses device 0 and the ranks talk over gloo through host
+    # memory.  It exercises this script's multi-rank control flow; its numbers mean nothing.
+    rehearsal = multi and os.environ.get("RT_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
+    comm_dev = torch.device("cpu") if rehearsal else dev
     if multi:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     w, h = args.width, args.height
-    ctx = rt.Context(local_rank)
+    ctx = rt.Context(dev_index)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
 
@@ -121,11 +130,12 @@ def main():
 
         blob0 = opts0 = cam0 = None
         if rank == 0:
-            blob0 = torch.from_numpy(ctx.pack(scene.desc)).to(dev)
+            blob0 = torch.from_numpy(ctx.pack(scene.desc)).to(comm_dev)
             opts0 = bytes(scene.opts.contents)
             cam = scene.camera.contents
             cam0 = list(cam.orig) + list(cam.camera)
-        blob, opts_raw, cam_f = mg.share_scene(blob0, opts0, cam0, rank, world, dev)  # RCCL over xGMI: scene + BVH, once
+        blob, opts_raw, cam_f = mg.share_scene(blob0, opts0, cam0, rank, world, comm_dev)  # RCCL over xGMI: scene + BVH, once
+        blob = blob.to(dev)
         torch.cuda.synchronize(dev)
         dscene = ctx.adopt_blob(blob.data_ptr(), blob.numel())
         opts = rt.RtDeviceOpts.from_buffer_copy(opts_raw)
@@ -143,17 +153,17 @@ def main():
     # ---- frame buffers (torch owns the memory; the library gets raw pointers) ----
     # One surface per frame in flight, like a swap chain: frame i renders into surface i % F while
     # frame i-1 is still draining and (with N > 1) being gathered.
-    nf = max(1, min(args.frames_in_flight, 4))
+    nf = max(1, min(args.frames_in_flight, 4)) if args.frames_in_flight > 0 else (4 if multi else 2)
     surfaces = [torch.zeros((h, w, 4), dtype=torch.float32, device=dev) for _ in range(nf)]
     surface = surfaces[0]
     pitch = w * 16
-    gatherer = mg.TileGather(w, h, rank, world, dev) if multi else None
+    gatherer = mg.TileGather(w, h, rank, world, comm_dev) if multi else None
     issued = [0]
 
     def collect(frames_ago):
         """Orders torch's stream behind the frame issued `frames_ago` calls ago and gathers its tiles to rank 0."""
         ctx.stream_wait_frame(stream.cuda_stream, frames_ago)
-        gatherer.gather(surfaces[(issued[0] - 1 - frames_ago) % nf])
+        gatherer.gather(surfaces[(issued[0] - 1 - frames_ago) % nf].to(comm_dev))
 
     def step():
         ctx.render(dscene, opts, camera_ref, surfaces[issued[0] % nf].data_ptr(), pitch, None, None, rank, world)
@@ -172,6 +182,7 @@ def main():
     ctx.render(dscene, opts, camera_ref, surface.data_ptr(), pitch, None, cnt_buf.data_ptr(), rank, world)
     torch.cuda.synchronize(dev)
     if multi:
+        cnt_buf = cnt_buf.to(comm_dev)
         dist.all_reduce(cnt_buf)
     cnt = {name: int(cnt_buf[i].item()) for i, name in enumerate(rt.RT_COUNTER_NAMES)}
     rays = cnt["primary"] + cnt["shadow"]
@@ -202,7 +213,7 @@ def main():
     # per-stage averages measured with HIP events on the library's stream: [closest-hit trace, shade, shadow trace, rest]
     t_stage = [kernel_ms / launches] + [x / launches for x in stages]
     if multi:
-        t = torch.tensor([elapsed] + t_stage, dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed] + t_stage, dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, t_stage = float(t[0].item()), [float(x) for x in t[1:].tolist()]
     frame_ms, closest_ms, shade_ms, shadow_ms, rest_ms = t_stage
@@ -245,7 +256,7 @@ def main():
             "kernel_ms": {"frame": frame_ms, "trace_closest": closest_ms, "shade": shade_ms, "trace_shadow": shadow_ms, "rest": rest_ms},
             "roofline": {"bound": "hbm", "kernel": "traceKernel<false,false> (closest hit, primary rays)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("traceKernel<false, false>", wl_key),
+                         "traffic": pmc_traffic("traceKernel<false, false>", wl_key) if world == 1 else None,
                          "algorithmic_bytes_per_launch": closest_bytes // world,
                          "other_kernels": {"traceKernel<true,false> (shadow, any hit)": {"achieved": gbs(shadow_bytes, shadow_ms),
                                                                                          "algorithmic_bytes_per_launch": shadow_bytes // world},

@@ -93,6 +93,67 @@ def probes():
           "total internal reflection", int((r["fr_refr"] == 0).all(1).sum()))
 
 
+def texture_inputs():
+    """A 4x4 RGBA8 texture and sample positions around every texel edge, the borders and beyond [0, 1]."""
+    rng = np.random.default_rng(7)
+    texels = rng.integers(0, 256, (4, 4, 4), dtype=np.uint8)
+    g = np.linspace(-0.3, 1.3, 33, dtype=np.float32)
+    uv = np.stack(np.meshgrid(g, g, indexing="ij"), axis=-1).reshape(-1, 2).astype(np.float32)
+    return texels, uv
+
+
+def eval_texture(texels, uv, mode):
+    """oracle_tex_sample over the positions; mode 0 = WRAP, 1 = CLAMP (cudaTracer/Texture.cuh:12)."""
+    from cudaraytracer_amd import _native as N
+
+    lib = pyoracle.load()
+    buf = (C.c_ubyte * texels.size).from_buffer_copy(texels.tobytes())
+    t = N.RtTexture(texels.shape[1], texels.shape[0], C.cast(buf, C.POINTER(C.c_ubyte)), mode)
+    out = np.zeros((len(uv), 3), dtype=np.float32)
+    o3 = (C.c_float * 3)()
+    for i, (u, v) in enumerate(uv):
+        lib.oracle_tex_sample(C.addressof(t), float(u), float(v), o3)
+        out[i] = list(o3)
+    return out
+
+
+def bvh_inputs(n=1000):
+    rng = np.random.default_rng(99)
+    c = rng.uniform(-20, 20, (n, 1, 3))
+    return (c + rng.uniform(-0.7, 0.7, (n, 3, 3))).astype(np.float32)  # [n][3 corners][xyz]
+
+
+def eval_bvh(corners, tight):
+    """The oracle's restatement of cudaTracer/BVH.h over a de-indexed triangle list: node bytes + leaf order."""
+    from cudaraytracer_amd import _native as N
+
+    lib = pyoracle.load()
+    n = len(corners)
+    verts = (N.RtVertex * (3 * n))()
+    tris = (N.RtTriangle * n)()
+    flat = corners.reshape(-1, 3)
+    for i in range(3 * n):
+        verts[i].position[:] = [float(x) for x in flat[i]]
+    for t in range(n):
+        tris[t].i[:] = [3 * t, 3 * t + 1, 3 * t + 2]
+    nodes = (N.RtLinearNode * (2 * n))()
+    cnt = C.c_int()
+    order = (C.c_int * n)()
+    assert lib.oracle_bvh_triangles(C.addressof(verts), C.addressof(tris), n, 10, tight, C.addressof(nodes), C.byref(cnt), C.addressof(order)) == 0
+    return np.frombuffer(bytes(nodes)[: 32 * cnt.value], dtype=np.uint8).copy(), np.array(list(order), dtype=np.int32)
+
+
+def tables():
+    texels, uv = texture_inputs()
+    corners = bvh_inputs()
+    nodes_ref, order_ref = eval_bvh(corners, 0)
+    nodes_tight, order_tight = eval_bvh(corners, 1)
+    np.savez_compressed(os.path.join(HERE, "tables.npz"), texels=texels, uv=uv, wrap=eval_texture(texels, uv, 0), clamp=eval_texture(texels, uv, 1),
+                        corners=corners, nodes_ref=nodes_ref, order_ref=order_ref, nodes_tight=nodes_tight, order_tight=order_tight)
+    print("tables:", len(uv), "texture samples per mode,", len(nodes_ref) // 32, "BVH nodes")
+
+
 if __name__ == "__main__":
+    tables()
     frames()
     probes()
