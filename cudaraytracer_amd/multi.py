@@ -58,7 +58,10 @@ def share_scene(blob, opts_bytes, camera_floats, rank, world, device):
 
 
 class TileGather:
-    """Collects the tiles each rank rendered into the full frame on rank 0.  Frame sizes must be multiples of 8."""
+    """Collects the tiles each rank rendered into the full frame on rank 0.  Frame sizes must be multiples of 8.
+
+    Rank 0 receives every peer's tiles straight into one [world, tiles per rank, 8, 8, c] buffer (one irecv per peer,
+    all in flight together) and interleaves them into tile order with a single strided copy."""
 
     def __init__(self, width, height, rank, world, device, channels=4, dtype=torch.float32):
         if width % TILE or height % TILE:
@@ -66,16 +69,18 @@ class TileGather:
         self.w, self.h, self.rank, self.world = width, height, rank, world
         self.tx, self.ty = tile_grid(width, height)
         self.c = channels
+        self.n = self.tx * self.ty
+        self.full = self.n // world  # tiles every rank has
+        self.rem = self.n % world    # ranks below this have one more
         self.mine = tile_ids(width, height, rank, world).to(device)
-        self.recv = None
         if rank == 0:
-            self.recv = [None] + [torch.empty((tile_count(width, height, r, world), TILE, TILE, channels), dtype=dtype, device=device)
-                                  for r in range(1, world)]
+            per = self.full + (1 if self.rem else 0)
+            self.buf = torch.zeros((world, per, TILE, TILE, channels), dtype=dtype, device=device)
             self.frame = torch.zeros((self.ty, self.tx, TILE, TILE, channels), dtype=dtype, device=device)
 
     def tiles(self, surface):
         """[h, w, c] surface -> [tiles, 8, 8, c] of this rank's tiles (a copy)."""
-        t = surface.view(self.ty, TILE, self.tx, TILE, self.c).permute(0, 2, 1, 3, 4).reshape(self.tx * self.ty, TILE, TILE, self.c)
+        t = surface.view(self.ty, TILE, self.tx, TILE, self.c).permute(0, 2, 1, 3, 4).reshape(self.n, TILE, TILE, self.c)
         return t.index_select(0, self.mine)
 
     def gather(self, surface):
@@ -84,10 +89,13 @@ class TileGather:
         if self.rank != 0:
             dist.send(mine, dst=0)
             return None
-        reqs = [dist.irecv(self.recv[r], src=r) for r in range(1, self.world)]
-        flat = self.frame.view(self.tx * self.ty, TILE, TILE, self.c)
-        flat[0::self.world] = mine
-        for r, q in enumerate(reqs, start=1):
+        reqs = [dist.irecv(self.buf[r, :tile_count(self.w, self.h, r, self.world)], src=r) for r in range(1, self.world)]
+        self.buf[0, :mine.shape[0]] = mine
+        for q in reqs:
             q.wait()
-            flat[r::self.world] = self.recv[r]
+        flat = self.frame.view(self.n, TILE, TILE, self.c)
+        # tile k * world + r sits in buf[r, k]
+        flat[: self.full * self.world] = self.buf[:, : self.full].transpose(0, 1).reshape(self.full * self.world, TILE, TILE, self.c)
+        if self.rem:
+            flat[self.full * self.world:] = self.buf[: self.rem, self.full]
         return self.frame.permute(0, 2, 1, 3, 4).reshape(self.h, self.w, self.c)
