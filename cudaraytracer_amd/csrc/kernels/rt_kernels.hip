@@ -219,6 +219,9 @@ constexpr unsigned TAG_TRI = 0x80000000u, TAG_SHAPE = 0xC0000000u, IDX_MASK = 0x
 constexpr unsigned STACK_MESH_EXIT = 0xFFFFFFFDu;  // stack marker: the mesh walk is over, restore the world-space ray
 constexpr int HIT_PENDING = -3;                    // hShape while the hit mesh is still being walked
 
+#ifndef RT_POP_WHILE
+#define RT_POP_WHILE if  // one pop attempt per iteration of the main loop (`while` = pop until something is entered)
+#endif
 #ifndef RT_TRI_PART
 #define RT_TRI_PART 16  // rays whose leaves are tested in one cooperative triangle phase (8 lanes each, 8 rays per round)
 #endif
@@ -584,7 +587,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                 }
             }
             // ========================= stack pops ============================
-            while (cur == CUR_POP) {
+            RT_POP_WHILE (cur == CUR_POP) {
                 if (sp == 0) {
                     cur = CUR_DONE;
                 } else {
