@@ -112,6 +112,7 @@ C_ABI = {
     "rt_stream_wait_frame": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rt_set_trace_waves": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_tile_order": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_set_sample_seed": (C.c_int, [C.c_void_p, C.c_uint32]),
 }
 
 HARNESS = {

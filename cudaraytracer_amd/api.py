@@ -225,6 +225,9 @@ class Context:
     def set_trace_waves(self, waves_per_cu):
         self._check(self.lib.rt_set_trace_waves(self.ctx, waves_per_cu), "rt_set_trace_waves")
 
+    def set_sample_seed(self, seed):
+        self._check(self.lib.rt_set_sample_seed(self.ctx, seed), "rt_set_sample_seed")
+
     def set_tile_order(self, mode):
         """0 = row-major, 1 = centre-out (default)."""
         self._check(self.lib.rt_set_tile_order(self.ctx, mode), "rt_set_tile_order")

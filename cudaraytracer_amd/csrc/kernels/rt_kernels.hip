@@ -154,24 +154,35 @@ __device__ __forceinline__ V3 invBiasedOrigin(V3 dir, V3 P, V3 n, float bias) {
 }
 
 // ---------------------------------------------------------------------------
-// Level-0 node -> pixel.  Node s of this call is lane (s & 63) of local tile
-// s >> 6; local tile k is frame tile tileFirst + k * tileStride (row-major), or tileOrder[k] when the
-// host supplies an order (the same set of tiles, expensive image regions first).
+// Level-0 node -> pixel.  With S = opts.samples, node s of this call is lane (s & 63) of sample (s >> 6) % S
+// of local tile (s >> 6) / S; local tile k is frame tile tileFirst + k * tileStride (row-major), or
+// tileOrder[k] when the host supplies an order (the same set of tiles, expensive image regions first).
 __device__ __forceinline__ bool slotPixel(const FrameParams& P, int slot, int& x, int& y) {
-    const int tile = P.tileOrder ? P.tileOrder[slot >> 6] : P.tileFirst + (slot >> 6) * P.tileStride;
+    const int group = slot >> 6;
+    const int local = P.opts.samples == 1 ? group : group / P.opts.samples;
+    const int tile = P.tileOrder ? P.tileOrder[local] : P.tileFirst + local * P.tileStride;
     const int l = slot & 63;
     x = (tile % P.tilesX) * RT_TILE + (l & (RT_TILE - 1));
     y = (tile / P.tilesX) * RT_TILE + (l >> 3);
     return x < P.opts.width && y < P.opts.height;
 }
+__device__ __forceinline__ int slotSample(const FrameParams& P, int slot) {
+    return P.opts.samples == 1 ? 0 : (slot >> 6) % P.opts.samples;
+}
 
-// Primary ray direction, cudaTracer/Main.cu:57-75 with samples == 1 (both jitters are exactly 0.0f).
-__device__ __forceinline__ V3 primaryDir(const FrameParams& P, int x, int y) {
+// Primary ray direction, cudaTracer/Main.cu:57-75.  With one sample both jitters are exactly 0.0f.
+__device__ __forceinline__ V3 primaryDir(const FrameParams& P, int x, int y, int sample) {
     const float widthScale = 1.0f / (float)P.opts.width;
     const float heightScale = 1.0f / (float)P.opts.height;
     const float ndcX = (2.0f * ((float)x + 0.5f) * widthScale - 1.0f) * P.opts.imageAspectRatio * P.opts.scale;
     const float ndcY = (1.0f - 2.0f * ((float)y + 0.5f) * heightScale) * P.opts.scale;
-    V3 dir = normalized(mk(ndcX + 0.0f * widthScale, ndcY + 0.0f * heightScale, 1.0f));
+    float xJitter = 0.0f, yJitter = 0.0f;
+    if (P.opts.samples > 1) {
+        const uint32_t pixel = (uint32_t)y * (uint32_t)P.opts.width + (uint32_t)x;
+        xJitter = rt_sample_jitter(P.sampleSeed, pixel, (uint32_t)sample, 0u);
+        yJitter = rt_sample_jitter(P.sampleSeed, pixel, (uint32_t)sample, 1u);
+    }
+    V3 dir = normalized(mk(ndcX + xJitter * widthScale, ndcY + yJitter * heightScale, 1.0f));
     const float* C = P.camera;
     dir = mk((dir.x * C[0] + dir.y * C[4]) + dir.z * C[8], (dir.x * C[1] + dir.y * C[5]) + dir.z * C[9],
              (dir.x * C[2] + dir.y * C[6]) + dir.z * C[10]);
@@ -184,7 +195,7 @@ __device__ __forceinline__ void nodeRay(const FrameParams& P, int node, V3& o, V
         int x, y;
         slotPixel(P, node, x, y);
         o = mk(P.orig);
-        d = primaryDir(P, x, y);
+        d = primaryDir(P, x, y, slotSample(P, node));
     } else {
         const float4* r = P.secRay + 2 * (size_t)(node - P.slots);
         o = mk(r[0]);
@@ -789,7 +800,7 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams P, const in
             } else if (shapeSlot < 0) {
                 P.color[node] = make_float4(bg.x, bg.y, bg.z, 0.0f);
                 P.kind[node] = NODE_DONE;
-                if (level == 0 && P.hitKeys) {
+                if (level == 0 && P.hitKeys && slotSample(P, node) == 0) {
                     int x, y;
                     slotPixel(P, node, x, y);
                     *reinterpret_cast<int4*>(P.hitKeys + ((size_t)y * P.opts.width + x) * 4) = make_int4(-1, -1, -1, -1);
@@ -814,7 +825,7 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams P, const in
                     key.w = rec->idx[2];
                     if (COUNT) cMesh++;
                 }
-                if (level == 0 && P.hitKeys) {
+                if (level == 0 && P.hitKeys && slotSample(P, node) == 0) {
                     int x, y;
                     slotPixel(P, node, x, y);
                     *reinterpret_cast<int4*>(P.hitKeys + ((size_t)y * P.opts.width + x) * 4) = key;
@@ -973,11 +984,16 @@ __global__ void __launch_bounds__(256) resolveKernel(const FrameParams P, const 
 
 // cudaTracer/Main.cu:66-98: sample sum (from 0), average, gamma, store.
 __global__ void __launch_bounds__(256) finalizeKernel(const FrameParams P) {
-    for (unsigned s = blockIdx.x * blockDim.x + threadIdx.x; s < (unsigned)P.slots; s += gridDim.x * blockDim.x) {
+    const int S = P.opts.samples;
+    const unsigned pixels = (unsigned)(P.slots / S);  // 64 per tile
+    for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += gridDim.x * blockDim.x) {
+        const unsigned first = ((p >> 6) * (unsigned)S << 6) | (p & 63u);  // the pixel's node of sample 0
         int x, y;
-        if (!slotPixel(P, (int)s, x, y)) continue;
-        V3 col = add(mk(0.0f, 0.0f, 0.0f), mk(P.color[s]));
-        const float samples = (float)P.opts.samples;
+        if (!slotPixel(P, (int)first, x, y)) continue;
+        // cudaTracer/Main.cu:66-82: the samples are added up in order, starting from zero, then divided
+        V3 col = mk(0.0f, 0.0f, 0.0f);
+        for (int i = 0; i < S; ++i) col = add(col, mk(P.color[first + ((unsigned)i << 6)]));
+        const float samples = (float)S;
         col = mk(col.x / samples, col.y / samples, col.z / samples);
         float4 out;
         if (P.opts.gammaCorrection) {

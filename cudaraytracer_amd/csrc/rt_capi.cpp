@@ -74,6 +74,7 @@ struct rt_ctx {
     int pathBudget = 3;  // node arrays hold pathBudget x pixels when the scene has mirror / glass materials
     int ldsStack = RT_LDS_STACK_DEFAULT;  // traversal stack entries kept in LDS (older ones move to global memory)
     int maxWavesPerCu = 0;                // 0 = as many as are resident
+    uint32_t sampleSeed = 1234;
     int tileOrderMode = RT_TILE_ORDER_CENTER_OUT;
     std::vector<int32_t> tileOrderHost;
     void* tileOrderDev = nullptr;
@@ -538,6 +539,12 @@ int rt_set_trace_waves(rt_ctx* ctx, int wavesPerCu) {
     return RT_OK;
 }
 
+int rt_set_sample_seed(rt_ctx* ctx, uint32_t seed) {
+    if (!ctx) return RT_ERR_INVALID;
+    ctx->sampleSeed = seed;
+    return RT_OK;
+}
+
 int rt_set_tile_order(rt_ctx* ctx, int mode) {
     if (!ctx) return RT_ERR_INVALID;
     if (mode != RT_TILE_ORDER_ROW_MAJOR && mode != RT_TILE_ORDER_CENTER_OUT) return fail(ctx, RT_ERR_INVALID, "unknown tile order %d", mode);
@@ -723,8 +730,7 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     if (opts->width < 1 || opts->height < 1) return fail(ctx, RT_ERR_INVALID, "bad frame size %dx%d", opts->width, opts->height);
     if (pitch < (size_t)opts->width * 16 || pitch % 16 != 0 || (reinterpret_cast<uintptr_t>(devSurface) & 15))
         return fail(ctx, RT_ERR_INVALID, "surface pitch/alignment must hold %d float4 pixels per row, 16-byte aligned", opts->width);
-    if (opts->samples != 1)
-        return fail(ctx, RT_ERR_INVALID, "samples must be 1 (the reference's multi-sample jitter is not reproducible)");
+    if (opts->samples < 1 || opts->samples > RT_MAX_SAMPLES) return fail(ctx, RT_ERR_INVALID, "samples %d outside 1..%d", opts->samples, RT_MAX_SAMPLES);
     if (opts->maxDepth < 0 || opts->maxDepth > RT_MAX_DEPTH)
         return fail(ctx, RT_ERR_LIMIT, "maxDepth %d outside 0..%d", opts->maxDepth, RT_MAX_DEPTH);
     const BlobHeader& hd = scene->header;
@@ -755,7 +761,7 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     if (myTiles <= 0) return RT_OK;
     const int secondary = hd.hasSecondary ? 1 : 0;
     const int budget = secondary && opts->maxDepth > 0 ? ctx->pathBudget : 1;
-    if (myTiles * RT_TILE * RT_TILE * budget > 0x7fffffffLL / 4) return fail(ctx, RT_ERR_LIMIT, "frame too large for 32-bit node indices");
+    if (myTiles * RT_TILE * RT_TILE * budget * opts->samples > 0x7fffffffLL / 4) return fail(ctx, RT_ERR_LIMIT, "frame too large for 32-bit node indices");
     p.stackEntries = hd.sceneDepth + hd.maxMeshDepth + 2;
     p.sceneRootRef = hd.sceneRootRef;
     p.offRecords = hd.offRecords;
@@ -773,7 +779,8 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     p.tileFirst = tileFirst;
     p.tileStride = tileStride;
     p.tileCnt = (int)myTiles;
-    p.slots = p.tileCnt * RT_TILE * RT_TILE;
+    p.slots = p.tileCnt * RT_TILE * RT_TILE * opts->samples;
+    p.sampleSeed = ctx->sampleSeed;
     p.nodeCap = p.slots * budget;
 
     // The frame's slot: with one frame in flight it runs on the context's stream, in order.  With

@@ -29,7 +29,8 @@
 // nodes.  A path node is one invocation of the reference's recursive castRay
 // (cudaTracer/tracer.cu:15-48): level-0 nodes are the pixels of the tiles this
 // call renders (64 per 8x8 tile), deeper nodes are reflection / refraction
-// children, appended per level.  Per level the driver runs
+// children, appended per level.  With S samples per pixel, level-0 node s is lane (s & 63) of
+// sample (s >> 6) % S of local tile (s >> 6) / S.  Per level the driver runs
 //   trace (closest hit) -> shade -> trace (any hit, shadow rays) -> accumulate
 // and finally resolves mirror / glass nodes bottom-up and writes the pixels.
 #ifndef RT_DEVICE_FORMAT_H
@@ -167,7 +168,8 @@ struct FrameParams {
     int32_t tilesX, tilesY;
     int32_t tileFirst, tileStride, tileCnt;  // this call renders tiles tileFirst + k*tileStride, k < tileCnt
     const int32_t* tileOrder;                // optional [tileCnt]: frame tile of local tile k (overrides the arithmetic rule)
-    int32_t slots;                           // tileCnt * 64 level-0 nodes
+    int32_t slots;                           // tileCnt * samples * 64 level-0 nodes
+    uint32_t sampleSeed;
     int32_t nodeCap;                         // capacity of the per-node arrays
     int32_t stackEntries;                    // per-lane traversal stack entries needed (8 bytes each)
     int32_t stackLds;                        // size of the LDS ring holding the top of the stack (a power of two)

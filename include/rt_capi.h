@@ -160,6 +160,25 @@ typedef struct RtDeviceOpts {
     uint8_t pad_;
 } RtDeviceOpts;
 
+/* Sub-pixel jitter of sample `sample` (0-based) of pixel `pixel` (= y * width + x) along `axis` (0 = x, 1 = y),
+ * in [-0.5, 0.5); used when RtDeviceOpts.samples > 1.  The reference draws its jitter from curand states that are
+ * shared between thread blocks and divides in integers (cudaTracer/Main.cu:60-61,68-69,108-110), so its values are
+ * neither reproducible nor in [-0.5, 0.5); this counter-based hash replaces it.  `seed` is rt_set_sample_seed's. */
+#if defined(__HIPCC__)
+#define RT_HOST_DEVICE __host__ __device__
+#else
+#define RT_HOST_DEVICE
+#endif
+static inline RT_HOST_DEVICE uint32_t rt_hash32(uint32_t v) {
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+static inline RT_HOST_DEVICE float rt_sample_jitter(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t axis) {
+    const uint32_t h = rt_hash32(rt_hash32(pixel ^ seed) + (sample * 2u + axis) * 0x9E3779B9u);
+    return (float)(h >> 8) * (1.0f / 16777216.0f) - 0.5f;
+}
+
 /* Per-frame camera: Scene::orig and Scene::camera (cudaTracer/Scene.cuh:17-18),
  * filled by the caller as in cudaTracer/RayTracer.cpp:201-202. */
 typedef struct RtCamera {
@@ -282,6 +301,11 @@ int rt_timing_read_stages(rt_ctx* ctx, double* totalMs, double* stageMs, int* la
  * per-frame node arrays hold `nodesPerPixel` x pixels path nodes (default 3).
  * A frame that needs more reports RT_ERR_LIMIT from rt_sync. */
 int rt_set_path_budget(rt_ctx* ctx, int nodesPerPixel);
+
+/* Seed of the sub-pixel jitter used with samples > 1 (default 1234, the seed the reference gives curand,
+ * cudaTracer/Main.cu:127).  Change it per frame to accumulate independent samples over frames. */
+int rt_set_sample_seed(rt_ctx* ctx, uint32_t seed);
+#define RT_MAX_SAMPLES 64
 
 /* Order in which a call's 8x8 tiles enter the trace kernels' work queue.  Which tiles
  * are rendered and every pixel value are the same either way.  CENTER_OUT (default)

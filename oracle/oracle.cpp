@@ -36,8 +36,9 @@
 //   * `sqrt` in solveQuadratic (cudaTracer/Sphere.cuh:18) is the float
 //     overload under nvcc; sqrtf is used here.
 //   * samples > 1 uses a jitter RNG that is racy and unseeded per pixel in the
-//     reference (cudaTracer/Main.cu:60-61,108-110); only samples == 1 is
-//     supported.
+//     reference (cudaTracer/Main.cu:60-61,108-110); rt_sample_jitter
+//     (include/rt_capi.h) stands in for it, so frames with samples > 1 have no
+//     counterpart in the reference at all (PARITY UNPINNED by construction).
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -423,6 +424,7 @@ struct Ctx {
     V3 orig;
     M44 camera;
     bool shadowAnyHit;
+    uint32_t sampleSeed;
     Counters* cnt;
 };
 
@@ -761,7 +763,8 @@ static V3 castRay(const Ctx& cx, Ray& ray, int depth, int32_t* primaryKey) {  //
     }
 }
 
-// Main.cu:43-98 for one pixel (samples == 1: both jitters are 0.0f)
+// Main.cu:43-98 for one pixel.  With samples == 1 both jitters are 0.0f; with more, the jitter is
+// rt_sample_jitter (include/rt_capi.h), which replaces the reference's irreproducible curand draw.
 static void renderPixel(const Ctx& cx, int x, int y, float* rgba, int32_t* key) {
     const RtDeviceOpts& o = cx.opts;
     float widthScale = 1 / (float)o.width;
@@ -769,14 +772,18 @@ static void renderPixel(const Ctx& cx, int x, int y, float* rgba, int32_t* key) 
     float ndcX = (2.0f * (x + 0.5f) * widthScale - 1.0f) * o.imageAspectRatio * o.scale;
     float ndcY = (1.0f - 2.0f * (y + 0.5f) * heightScale) * o.scale;
     V3 pixCol = mk(0, 0, 0);
-    float xJitter = 0.0f, yJitter = 0.0f;
-    V3 dir = normalized(mk(ndcX + xJitter * widthScale, ndcY + yJitter * heightScale, 1));
-    dir = multVec(cx.camera, dir);
-    dir = normalized(dir);
-    Ray ray = mkRay(cx.orig, dir);
     if (key) key[0] = key[1] = key[2] = key[3] = -1;
-    if (cx.cnt) cx.cnt->c[RT_CNT_PRIMARY]++;
-    pixCol = add(pixCol, castRay(cx, ray, 0, key));
+    for (int i = 0; i < o.samples; ++i) {
+        const uint32_t pixel = (uint32_t)y * (uint32_t)o.width + (uint32_t)x;
+        float xJitter = o.samples > 1 ? rt_sample_jitter(cx.sampleSeed, pixel, (uint32_t)i, 0u) : 0.0f;
+        float yJitter = o.samples > 1 ? rt_sample_jitter(cx.sampleSeed, pixel, (uint32_t)i, 1u) : 0.0f;
+        V3 dir = normalized(mk(ndcX + xJitter * widthScale, ndcY + yJitter * heightScale, 1));
+        dir = multVec(cx.camera, dir);
+        dir = normalized(dir);
+        Ray ray = mkRay(cx.orig, dir);
+        if (cx.cnt) cx.cnt->c[RT_CNT_PRIMARY]++;
+        pixCol = add(pixCol, castRay(cx, ray, 0, i == 0 ? key : nullptr));  // the hit key is sample 0's
+    }
     for (int i = 0; i < 3; ++i) pixCol[i] /= o.samples;
     if (o.gammaCorrection) {
         const float screenGamma = 2.2;
@@ -797,7 +804,11 @@ static void renderPixel(const Ctx& cx, int x, int y, float* rgba, int32_t* key) 
 // =========================================================================
 // C entry points (loaded with ctypes by the tests and the bench baseline)
 // =========================================================================
+static uint32_t g_sampleSeed = 1234;  // the product's default (rt_set_sample_seed)
+
 extern "C" {
+
+void oracle_set_sample_seed(uint32_t seed) { g_sampleSeed = seed; }
 
 // Renders rows y = y0, y0+yStep, ... < y1 of the frame into tight
 // width*height*4 float / int32 planes (other rows untouched).  Rows are dealt
@@ -807,7 +818,7 @@ extern "C" {
 int oracle_render(const RtSceneDesc* scene, const RtDeviceOpts* opts, const RtCamera* cam, float* rgba,
                   int32_t* hitKeys, uint64_t* counters, int y0, int y1, int yStep, int nThreads,
                   int shadowAnyHit) {
-    if (!scene || !opts || !cam || !rgba || opts->samples != 1 || yStep < 1) return -1;
+    if (!scene || !opts || !cam || !rgba || opts->samples < 1 || yStep < 1) return -1;
     if (nThreads < 1) nThreads = 1;
     std::vector<int> rows;
     for (int y = y0; y < y1 && y < opts->height; y += yStep) rows.push_back(y);
@@ -819,6 +830,7 @@ int oracle_render(const RtSceneDesc* scene, const RtDeviceOpts* opts, const RtCa
         cx.orig = ora::mk(cam->orig);
         cx.camera = ora::fromRowMajor(cam->camera);
         cx.shadowAnyHit = shadowAnyHit != 0;
+        cx.sampleSeed = g_sampleSeed;
         cx.cnt = counters ? &cnts[tid] : nullptr;
         for (size_t r = tid; r < rows.size(); r += nThreads) {
             int y = rows[r];

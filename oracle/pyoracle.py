@@ -44,6 +44,8 @@ def load():
         lib.oracle_mat_inverse.restype = None
         lib.oracle_mat_inverse.argtypes = [f3, f3]
         lib.oracle_box_pad_factor.restype = C.c_float
+        lib.oracle_set_sample_seed.restype = None
+        lib.oracle_set_sample_seed.argtypes = [C.c_uint32]
         _lib = lib
     return _lib
 
