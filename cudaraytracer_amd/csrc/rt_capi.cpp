@@ -645,10 +645,9 @@ int rt_scene_set_lights(rt_scene* scene, const RtLight* lights, int lightCnt) {
     if (!lights || lightCnt != scene->header.lightCnt)
         return fail(ctx, RT_ERR_INVALID, "light count must stay %d", scene->header.lightCnt);
     if (int r = bind(ctx)) return r;
-    // stream-ordered so that frames already queued keep the lights they were issued with
-    RT_HIP(ctx, hipMemcpyAsync(scene->blob + scene->header.offLights, lights, (size_t)lightCnt * sizeof(RtLight),
-                               hipMemcpyHostToDevice, ctx->stream));
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // frames already issued (on the context's stream or on the in-flight slots) keep the lights they were issued with
+    if (int r = syncFrames(ctx)) return r;
+    RT_HIP(ctx, hipMemcpy(scene->blob + scene->header.offLights, lights, (size_t)lightCnt * sizeof(RtLight), hipMemcpyHostToDevice));
     return RT_OK;
 }
 
@@ -656,7 +655,7 @@ void rt_scene_free(rt_scene* scene) {
     if (!scene) return;
     if (scene->ownsBlob) {
         hipSetDevice(scene->ctx->device);
-        hipStreamSynchronize(scene->ctx->stream);
+        (void)syncFrames(scene->ctx);  // frames in flight may still read the blob
         hipFree(scene->blob);
     }
     delete scene;
@@ -679,7 +678,7 @@ int rt_surface_download(rt_ctx* ctx, const void* devSurface, size_t pitch, int w
     if (!ctx) return RT_ERR_INVALID;
     if (!devSurface || !hostRgba || pitch < (size_t)width * 16) return fail(ctx, RT_ERR_INVALID, "bad download arguments");
     if (int r = bind(ctx)) return r;
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int r = syncFrames(ctx)) return r;
     RT_HIP(ctx, hipMemcpy2D(hostRgba, (size_t)width * 16, devSurface, pitch, (size_t)width * 16, height, hipMemcpyDeviceToHost));
     return RT_OK;
 }
@@ -701,7 +700,7 @@ int rt_device_download(rt_ctx* ctx, const void* devPtr, size_t bytes, void* host
     if (!ctx) return RT_ERR_INVALID;
     if (!devPtr || !host) return fail(ctx, RT_ERR_INVALID, "bad download arguments");
     if (int r = bind(ctx)) return r;
-    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (int r = syncFrames(ctx)) return r;
     RT_HIP(ctx, hipMemcpy(host, devPtr, bytes, hipMemcpyDeviceToHost));
     return RT_OK;
 }
@@ -717,7 +716,7 @@ int rt_device_zero(rt_ctx* ctx, void* devPtr, size_t bytes) {
 void rt_device_free(rt_ctx* ctx, void* devPtr) {
     if (!ctx || !devPtr) return;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    (void)syncFrames(ctx);  // frames in flight may still write the buffer
     hipFree(devPtr);
 }
 
