@@ -113,6 +113,7 @@ C_ABI = {
     "rt_set_trace_waves": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_tile_order": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_sample_seed": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rt_set_device_bvh": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
 }
 
 HARNESS = {

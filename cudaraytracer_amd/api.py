@@ -20,10 +20,10 @@ class HostScene:
     reference's FLT_MIN-clamped one (same hits except ties, far fewer tests).
     """
 
-    def __init__(self, name, width, height, size=0, lights=0, max_depth=0, asset_dir=None, tight_bvh=False):
+    def __init__(self, name, width, height, size=0, lights=0, max_depth=0, asset_dir=None, tight_bvh=False, device_bvh=False):
         self.lib = N.load()
         self.h = self.lib.rth_scene_create(name.encode(), width, height, size, lights, max_depth,
-                                           asset_dir.encode() if asset_dir else None, 1 if tight_bvh else 0)
+                                           asset_dir.encode() if asset_dir else None, (1 if tight_bvh else 0) | (2 if device_bvh else 0))
         if not self.h:
             raise RtError(self.lib.rth_last_error().decode())
         self.name = name
@@ -224,6 +224,10 @@ class Context:
 
     def set_trace_waves(self, waves_per_cu):
         self._check(self.lib.rt_set_trace_waves(self.ctx, waves_per_cu), "rt_set_trace_waves")
+
+    def set_device_bvh(self, threshold=10, tight_bounds=True):
+        """Parameters of the on-device BVH build used for meshes that come without nodes."""
+        self._check(self.lib.rt_set_device_bvh(self.ctx, threshold, 1 if tight_bounds else 0), "rt_set_device_bvh")
 
     def set_sample_seed(self, seed):
         self._check(self.lib.rt_set_sample_seed(self.ctx, seed), "rt_set_sample_seed")

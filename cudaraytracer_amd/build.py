@@ -55,15 +55,24 @@ def build_library(force=False, extra_device_flags=(), out=None, tag=""):
     objdir = os.path.join(PKG, "build" + tag)
     os.makedirs(objdir, exist_ok=True)
     objs = []
-    kern = os.path.join(CSRC, "kernels", "rt_kernels.hip")
-    o = os.path.join(objdir, "rt_kernels.o")
-    _run([HIPCC, *DEVICE_FLAGS, *extra_device_flags, "-c", kern, "-o", o])
-    objs.append(o)
+    headers = [f for f in _sources() if f.endswith(".h")]
+
+    def compile_one(src, obj, cmd):
+        # per-object rebuild: the source itself or any header changed (a forced build recompiles everything)
+        if force or _newer(obj, [src] + headers):
+            _run(cmd + ["-c", src, "-o", obj])
+        objs.append(obj)
+
+    compile_one(os.path.join(CSRC, "kernels", "rt_kernels.hip"), os.path.join(objdir, "rt_kernels.o"), [HIPCC, *DEVICE_FLAGS, *extra_device_flags])
+    # the BVH build kernels take no tuning flags; every variant links the default build's object
+    bvh_obj_dir = os.path.join(PKG, "build")
+    os.makedirs(bvh_obj_dir, exist_ok=True)
+    bvh_force, force = force, (force and not tag)
+    compile_one(os.path.join(CSRC, "kernels", "rt_bvh_build.hip"), os.path.join(bvh_obj_dir, "rt_bvh_build.o"), [HIPCC, *DEVICE_FLAGS])
+    force = bvh_force
     for rel in ("rt_capi.cpp", os.path.join("host", "harness.cpp"), os.path.join("host", "host_selftest.cpp")):
-        src = os.path.join(CSRC, rel)
-        o = os.path.join(objdir, os.path.basename(rel).replace(".cpp", ".o"))
-        _run([HIPCC, "-x", "c++", *HOST_FLAGS, "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c", src, "-o", o])
-        objs.append(o)
+        compile_one(os.path.join(CSRC, rel), os.path.join(objdir, os.path.basename(rel).replace(".cpp", ".o")),
+                    [HIPCC, "-x", "c++", *HOST_FLAGS, "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"])
     _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-lz"])
     return out
 

@@ -36,6 +36,26 @@ namespace BVH {
 
 enum BoundsMode { REFERENCE_BOUNDS = 0, TIGHT_BOUNDS = 1 };
 
+// How a mesh gets its BVH: built here on the host, or left to the device (rt_scene_upload builds the BVH of a
+// mesh that arrives without nodes; same algorithm, see include/rt_capi.h rt_set_device_bvh).
+struct BuildOptions {
+    BoundsMode bounds = REFERENCE_BOUNDS;
+    bool onDevice = false;
+    BuildOptions() = default;
+    BuildOptions(BoundsMode b, bool device = false) : bounds(b), onDevice(device) {}
+};
+
+// Depth of the deepest leaf of the median-cut tree over n primitives (the tree's shape depends on n alone).
+inline int medianTreeDepth(int n, int threshold) {
+    int depth = 0;
+    // the larger half decides: it holds n - n / 2 primitives
+    while (n > threshold) {
+        n = n - n / 2;
+        ++depth;
+    }
+    return depth;
+}
+
 inline BoundingBox emptyBox(BoundsMode mode) {
     return mode == TIGHT_BOUNDS ? BoundingBox(Vec3f(FLT_MAX, FLT_MAX, FLT_MAX), Vec3f(-FLT_MAX, -FLT_MAX, -FLT_MAX)) : BoundingBox();
 }

@@ -49,11 +49,13 @@ class DeviceMesh {
     Shape shape;
 
     BVH::BoundsMode boundsMode = BVH::REFERENCE_BOUNDS;
+    bool bvhOnDevice = false;  // nodes stay empty; rt_scene_upload builds the BVH on the GPU
+    BoundingBox rootBox;       // box of the whole mesh (object space)
 
     DeviceMesh(std::vector<Vertex> vertices, std::vector<int> indices, int /*triCnt*/, TextureSource diffuse,
                TextureSource normals, TextureSource specular, Texture::AddressingMode mode, Material material,
-               Mat44f transformation, BVH::BoundsMode bounds = BVH::REFERENCE_BOUNDS)
-        : boundsMode(bounds) {
+               Mat44f transformation, BVH::BuildOptions build = BVH::BuildOptions())
+        : boundsMode(build.bounds), bvhOnDevice(build.onDevice) {
         prepareGeometry(std::move(vertices), std::move(indices));
         createShape(diffuse, normals, specular, mode, material, transformation);
     }
@@ -61,8 +63,8 @@ class DeviceMesh {
     // First material of the model names the three maps; CLAMP addressing
     // (cudaTracer/CudaMesh.h:37-47).
     DeviceMesh(const model::Model& model, Material material, Mat44f transformation,
-               BVH::BoundsMode bounds = BVH::REFERENCE_BOUNDS)
-        : boundsMode(bounds) {
+               BVH::BuildOptions build = BVH::BuildOptions())
+        : boundsMode(build.bounds), bvhOnDevice(build.onDevice) {
         prepareGeometry(model.getVertices(), model.getIndices());
         if (model.getMaterials().empty()) throw std::invalid_argument("DeviceMesh: model without material");
         const model::Material& m = model.getMaterials()[0];
@@ -81,12 +83,26 @@ class DeviceMesh {
         std::vector<Triangle> tris;
         tris.reserve(indices.size() / 3);
         for (size_t i = 0; i < indices.size(); i += 3) tris.emplace_back(indices[i], indices[i + 1], indices[i + 2]);
+        if (bvhOnDevice) {
+            // triangles stay in index-list order (tangents of shared vertices then follow that order, not leaf order);
+            // the device orders its own copy
+            rootBox = BVH::emptyBox(boundsMode);
+            for (const Triangle& t : tris) rootBox = BoundingBox::unionn(rootBox, BVH::triangleBox(t, vertices, boundsMode));
+            triangles = std::move(tris);
+            triangleSource.resize(triangles.size());
+            for (size_t k = 0; k < triangleSource.size(); ++k) triangleSource[k] = (int)k;
+            generateTangents();
+            nodes.clear();
+            bvhDepth = BVH::medianTreeDepth((int)triangles.size(), 10);
+            return;
+        }
         BVH::BvhFactory<Triangle> bvh(vertices, tris, 10, boundsMode);
         triangles = std::move(bvh.orderedPrims);
         triangleSource = std::move(bvh.orderedIdx);
         generateTangents();
         nodes = std::move(bvh.nodes);
         bvhDepth = bvh.depth;
+        rootBox = nodes[0].bb;
     }
 
     void createShape(const TextureSource& diffuseSrc, const TextureSource& normalsSrc, const TextureSource& specularSrc,
@@ -94,11 +110,11 @@ class DeviceMesh {
         Texture diffuse = loadTexture(diffuseSrc, &diffuseData, mode);
         Texture normals = loadTexture(normalsSrc, &normalsData, mode);
         Texture specular = loadTexture(specularSrc, &specularData, mode);
-        mesh = Mesh(triangles.data(), (int)triangles.size(), vertices.data(), diffuse, normals, specular, nodes.data(),
+        mesh = Mesh(triangles.data(), (int)triangles.size(), vertices.data(), diffuse, normals, specular, nodes.empty() ? nullptr : nodes.data(),
                     transformation, (int)vertices.size(), (int)nodes.size());
         // World box = the two extreme corners of the root box, transformed
         // (cudaTracer/CudaMesh.h:77-79): exact for scale + translate, loose for rotations.
-        BoundingBox shapeBb = nodes[0].bb;
+        BoundingBox shapeBb = rootBox;
         shapeBb.bbmin = transformation.multPoint(shapeBb.bbmin);
         shapeBb.bbmax = transformation.multPoint(shapeBb.bbmax);
         shape = Shape(mesh, shapeBb);

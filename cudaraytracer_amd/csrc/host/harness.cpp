@@ -94,6 +94,7 @@ void ringLights(RayTracer& rt, int count, uint64_t seed) {
 }
 
 using BVH::BoundsMode;
+using BVH::BuildOptions;
 
 Options baseOptions(int width, int height, float fov, int maxDepth) {
     Options o = loadDefaults();
@@ -104,9 +105,9 @@ Options baseOptions(int width, int height, float fov, int maxDepth) {
 
 // cfg "cubes": n x n grid of unit cubes (CubeModelFactory tables), each its own
 // mesh with its own BVH, under a scene BVH; 1x1 textures; 4 fixed lights.
-std::unique_ptr<RayTracer> buildCubes(int width, int height, int n, int lightCnt, int maxDepth, BoundsMode bm) {
+std::unique_ptr<RayTracer> buildCubes(int width, int height, int n, int lightCnt, int maxDepth, BuildOptions bm) {
     if (n < 1) n = 16;
-    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 90, maxDepth), bm);
+    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 90, maxDepth), bm.bounds);
     const std::vector<Vertex> verts = CubeModelFactory::createVertices();
     const std::vector<int> inds = CubeModelFactory::createIndicies();
     Material mtl;
@@ -130,9 +131,9 @@ std::unique_ptr<RayTracer> buildCubes(int width, int height, int n, int lightCnt
 // cfg "soup": N random triangles in one mesh (de-indexed, like the OBJ reader
 // produces): centres U[-50,50]^3, two edges U[-0.75,0.75]^3, face normals,
 // UVs (0,0)(1,0)(0,1); PCG32 seed 1234; 16x16 procedural textures.
-std::unique_ptr<RayTracer> buildSoup(int width, int height, int triCnt, int lightCnt, int maxDepth, BoundsMode bm) {
+std::unique_ptr<RayTracer> buildSoup(int width, int height, int triCnt, int lightCnt, int maxDepth, BuildOptions bm) {
     if (triCnt < 1) triCnt = 1000000;
-    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 60, maxDepth), bm);
+    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 60, maxDepth), bm.bounds);
     Pcg32 rng(1234);
     std::vector<Vertex> verts;
     std::vector<int> inds;
@@ -169,10 +170,10 @@ std::unique_ptr<RayTracer> buildSoup(int width, int height, int triCnt, int ligh
 
 // cfg "heightfield": side x side quads of a sinusoidally displaced, jittered
 // height field in ONE mesh (2 triangles per quad, de-indexed).
-std::unique_ptr<RayTracer> buildHeightfield(int width, int height, int triCnt, int lightCnt, int maxDepth, BoundsMode bm) {
+std::unique_ptr<RayTracer> buildHeightfield(int width, int height, int triCnt, int lightCnt, int maxDepth, BuildOptions bm) {
     int side = (int)std::floor(std::sqrt((triCnt < 2 ? 9999392 : triCnt) / 2.0));
     if (side < 1) side = 1;
-    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 60, maxDepth), bm);
+    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 60, maxDepth), bm.bounds);
     Pcg32 rng(1234);
     const float extent = 200.0f, cell = extent / side;
     std::vector<float> hgt((size_t)(side + 1) * (side + 1));
@@ -222,8 +223,8 @@ std::unique_ptr<RayTracer> buildHeightfield(int width, int height, int triCnt, i
 // glass + textured plane + three mesh instances - with a deterministic light
 // ring.  With an asset directory the plane uses pattern_106 and the meshes are
 // the metal barrel; without one, procedural textures and cubes stand in.
-std::unique_ptr<RayTracer> buildMixed(int width, int height, int lightCnt, int maxDepth, const std::string& assets, BoundsMode bm) {
-    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 90, maxDepth), bm);
+std::unique_ptr<RayTracer> buildMixed(int width, int height, int lightCnt, int maxDepth, const std::string& assets, BuildOptions bm) {
+    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 90, maxDepth), bm.bounds);
     rt->addSpheres();
     const unsigned char ca[3] = {200, 200, 200}, cb[3] = {70, 70, 90};
     if (!assets.empty()) {
@@ -256,9 +257,9 @@ std::unique_ptr<RayTracer> buildMixed(int width, int height, int lightCnt, int m
 
 // cfg "barrel": the OBJ asset with its three PNG maps + textured plane + mirror
 // and glass balls + a mirror-material barrel instance.
-std::unique_ptr<RayTracer> buildBarrel(int width, int height, int lightCnt, int maxDepth, const std::string& assets, BoundsMode bm) {
+std::unique_ptr<RayTracer> buildBarrel(int width, int height, int lightCnt, int maxDepth, const std::string& assets, BuildOptions bm) {
     if (assets.empty()) throw std::invalid_argument("scene 'barrel' needs an asset directory");
-    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 90, maxDepth), bm);
+    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 90, maxDepth), bm.bounds);
     const Mat44f scale = Mat44f::scale(1 / 50.0f, 1 / 50.0f, 1 / 50.0f);
     const std::vector<model::Model> models = ObjFileReader().readFile(assets + "/models/metalBarrel/", "metal_barrel.obj", false);
     if (models.empty()) throw std::runtime_error("metal_barrel.obj: no model read");
@@ -309,7 +310,7 @@ const char* rth_last_error(void) { return g_error.c_str(); }
 rth_scene* rth_scene_create(const char* name, int width, int height, int size, int lightCnt, int maxDepth, const char* assetDir,
                             int flags) {
     try {
-        const BoundsMode bm = (flags & 1) ? BVH::TIGHT_BOUNDS : BVH::REFERENCE_BOUNDS;
+        const BuildOptions bm((flags & 1) ? BVH::TIGHT_BOUNDS : BVH::REFERENCE_BOUNDS, (flags & 2) != 0);
         const std::string n = name ? name : "";
         const std::string assets = assetDir ? assetDir : "";
         std::unique_ptr<RayTracer> rt;

@@ -1,0 +1,314 @@
+// rt_bvh_build.hip - mesh BVH construction on the GPU.
+//
+// Builds the same tree as the host builder (csrc/host/BVH.h, which follows
+// cudaTracer/BVH.h:104-181): a range of primitives becomes a leaf when it holds
+// <= threshold primitives, otherwise it is cut at mid = (start + end) / 2 after
+// ordering it by box centroid along the widest axis of the centroid bounds
+// (ties Z over Y over X, cudaTracer/BoundingBox.cuh:59-68).  Because the cut is
+// always the median position, the SHAPE of the tree depends only on the
+// primitive count: the host lays out the node records (references, leaf ranges)
+// beforehand, and the device only has to order the primitives and fill in
+// boxes and split axes.
+//
+// Level by level, every primitive walks the implicit tree to the range that
+// holds its position, the ranges' centroid bounds are reduced with atomics, and
+// ONE global radix sort per level orders all ranges at once (key = range id in
+// the high word, centroid coordinate in the low word; the range ids grow with
+// the position, so ranges stay where they are).  The reference selects the
+// median with nth_element; a full sort puts the same primitives on either side
+// whenever the median value is unique, so node boxes and axes are those of the
+// host builder, while the order inside a leaf may differ.
+//
+// Not reproduced: the reference turns a range whose centroids all coincide into
+// a leaf of any size (cudaTracer/BVH.h:126-128).  The device build reports such
+// a mesh instead (the caller falls back to the host builder).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <float.h>
+#include <stdint.h>
+
+#include "../rt_device_format.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// float <-> unsigned with the same ordering
+__device__ __forceinline__ uint32_t orderedBits(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fromOrderedBits(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+
+// Walks `levels` cuts down from the whole range towards position i.  Returns true if the range reached is
+// one that is cut at this level (more than `threshold` primitives).  `id` is the range's heap index (root 1);
+// a range that stopped being cut earlier keeps a unique id by continuing to the left.
+__device__ __forceinline__ bool descend(int i, int n, int threshold, int levels, int& s, int& e, uint32_t& id) {
+    s = 0;
+    e = n;
+    id = 1u;
+    for (int l = 0; l < levels; ++l) {
+        if (e - s <= threshold) {
+            id <<= (levels - l);
+            return false;
+        }
+        const int mid = (s + e) / 2;
+        if (i < mid) {
+            e = mid;
+            id = 2u * id;
+        } else {
+            s = mid;
+            id = 2u * id + 1u;
+        }
+    }
+    return e - s > threshold;
+}
+
+// csrc/host/BVH.h triangleBox: the reference box starts at (FLT_MAX, FLT_MIN), the tight one at (FLT_MAX, -FLT_MAX)
+__global__ void __launch_bounds__(kBlock) primBoundsKernel(int n, const int32_t* __restrict__ tris, const unsigned char* __restrict__ vertices,
+                                                           int tight, float4* __restrict__ bmin, float4* __restrict__ bmax) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+    const float top = tight ? -FLT_MAX : FLT_MIN;
+    float hi[3] = {top, top, top};
+    for (int c = 0; c < 3; ++c) {
+        const float* pos = reinterpret_cast<const float*>(vertices + (size_t)tris[3 * i + c] * sizeof(RtVertex) + 44);
+        for (int a = 0; a < 3; ++a) {
+            const float p = pos[a];
+            if (p > hi[a]) hi[a] = p;
+            if (p < lo[a]) lo[a] = p;
+        }
+    }
+    bmin[i] = make_float4(lo[0], lo[1], lo[2], 0.0f);
+    bmax[i] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+}
+
+__global__ void __launch_bounds__(kBlock) iotaKernel(int n, uint32_t* order) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) order[i] = (uint32_t)i;
+}
+
+// centroid bounds of an empty range: {min x, y, z, max x, y, z} as ordered bits
+__global__ void __launch_bounds__(kBlock) boundsInitKernel(uint32_t first, uint32_t count, int tight, uint32_t* cb) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    uint32_t* b = cb + 6 * (size_t)(first + k);
+    const uint32_t lo = orderedBits(FLT_MAX), hi = orderedBits(tight ? -FLT_MAX : FLT_MIN);
+    b[0] = b[1] = b[2] = lo;
+    b[3] = b[4] = b[5] = hi;
+}
+
+// BoundingBox::centroid(): (bbmin + bbmax) / 2
+__device__ __forceinline__ void centroidOf(const float4 lo, const float4 hi, float c[3]) {
+    c[0] = (lo.x + hi.x) / 2.0f;
+    c[1] = (lo.y + hi.y) / 2.0f;
+    c[2] = (lo.z + hi.z) / 2.0f;
+}
+
+__global__ void __launch_bounds__(kBlock) centroidBoundsKernel(int n, int threshold, int level, const uint32_t* __restrict__ order,
+                                                               const float4* __restrict__ bmin, const float4* __restrict__ bmax, uint32_t* cb) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int s, e;
+    uint32_t id;
+    if (!descend(i, n, threshold, level, s, e, id)) return;
+    const uint32_t prim = order[i];
+    float c[3];
+    centroidOf(bmin[prim], bmax[prim], c);
+    uint32_t* b = cb + 6 * (size_t)(id - 1u);
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t v = orderedBits(c[a]);
+        atomicMin(b + a, v);
+        atomicMax(b + 3 + a, v);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) sortKeyKernel(int n, int threshold, int level, const uint32_t* __restrict__ order,
+                                                        const float4* __restrict__ bmin, const float4* __restrict__ bmax,
+                                                        const uint32_t* __restrict__ cb, unsigned char* __restrict__ axisOut,
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ flags) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int s, e;
+    uint32_t id;
+    if (!descend(i, n, threshold, level, s, e, id)) {
+        keys[i] = (uint64_t)id << 32 | (uint32_t)(i - s);  // a finished range keeps its order
+        return;
+    }
+    const uint32_t* b = cb + 6 * (size_t)(id - 1u);
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = fromOrderedBits(b[a]);
+        hi[a] = fromOrderedBits(b[3 + a]);
+    }
+    // BoundingBox::maxExtent
+    const float d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
+    const int dim = (d0 > d1 && d0 > d2) ? 0 : (d1 > d2 ? 1 : 2);
+    if (hi[dim] == lo[dim]) atomicOr(flags, 1u);  // all centroids coincide: the reference makes this a leaf
+    if (i == s) axisOut[id - 1u] = (unsigned char)dim;
+    const uint32_t prim = order[i];
+    float c[3];
+    centroidOf(bmin[prim], bmax[prim], c);
+    keys[i] = (uint64_t)id << 32 | orderedBits(c[dim]);
+}
+
+// Per-node work table built by the host from the primitive count alone.
+struct BuildNode {
+    int32_t start, end;   // primitive positions of the node's range
+    int32_t rec;          // index of the node's 32-byte record in the mesh's node array
+    int32_t left, right;  // records of the children (-1 for a leaf)
+    uint32_t pathId;      // heap index of the range (root 1)
+};
+
+__global__ void __launch_bounds__(kBlock) leafBoxKernel(int count, const BuildNode* __restrict__ nodes, int tight, const uint32_t* __restrict__ order,
+                                                        const float4* __restrict__ bmin, const float4* __restrict__ bmax, float* __restrict__ records) {
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    const BuildNode nd = nodes[k];
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+    const float top = tight ? -FLT_MAX : FLT_MIN;
+    float hi[3] = {top, top, top};
+    for (int i = nd.start; i < nd.end; ++i) {
+        const uint32_t prim = order[i];
+        const float4 a = bmin[prim], b = bmax[prim];
+        lo[0] = fminf(lo[0], a.x); lo[1] = fminf(lo[1], a.y); lo[2] = fminf(lo[2], a.z);
+        hi[0] = fmaxf(hi[0], b.x); hi[1] = fmaxf(hi[1], b.y); hi[2] = fmaxf(hi[2], b.z);
+    }
+    float* r = records + 8 * (size_t)nd.rec;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2];
+    r[3] = hi[0]; r[4] = hi[1]; r[5] = hi[2];
+}
+
+// One level of interior nodes, deepest level first: box = union of the children, axis into the reference word.
+__global__ void __launch_bounds__(kBlock) interiorBoxKernel(int count, const BuildNode* __restrict__ nodes, const unsigned char* __restrict__ axisOf,
+                                                            float* __restrict__ records) {
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    const BuildNode nd = nodes[k];
+    const float* a = records + 8 * (size_t)nd.left;
+    const float* b = records + 8 * (size_t)nd.right;
+    float* r = records + 8 * (size_t)nd.rec;
+    for (int c = 0; c < 3; ++c) {
+        r[c] = fminf(a[c], b[c]);
+        r[3 + c] = fmaxf(a[3 + c], b[3 + c]);
+    }
+    uint32_t ref = __float_as_uint(r[6]);
+    ref = (ref & ~(3u << 29)) | ((uint32_t)axisOf[nd.pathId - 1u] << 29);
+    r[6] = __uint_as_float(ref);
+}
+
+// Triangle records in leaf order.  The host builder visits the second half of every range first
+// (cudaTracer/BVH.h:146-149), so the leaf over positions [s, e) owns ordered slots n - e ...
+__global__ void __launch_bounds__(kBlock) recordKernel(int n, int threshold, const uint32_t* __restrict__ order, const int32_t* __restrict__ tris,
+                                                       const unsigned char* __restrict__ vertices, TriRecord* __restrict__ records) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int s = 0, e = n;
+    while (e - s > threshold) {
+        const int mid = (s + e) / 2;
+        if (i < mid)
+            e = mid;
+        else
+            s = mid;
+    }
+    const uint32_t prim = order[i];
+    const int32_t i0 = tris[3 * prim], i1 = tris[3 * prim + 1], i2 = tris[3 * prim + 2];
+    const float* p0 = reinterpret_cast<const float*>(vertices + (size_t)i0 * sizeof(RtVertex) + 44);
+    const float* p1 = reinterpret_cast<const float*>(vertices + (size_t)i1 * sizeof(RtVertex) + 44);
+    const float* p2 = reinterpret_cast<const float*>(vertices + (size_t)i2 * sizeof(RtVertex) + 44);
+    TriRecord rec;
+    for (int k = 0; k < 3; ++k) {
+        rec.v0[k] = p0[k];
+        rec.e1[k] = p1[k] - p0[k];
+        rec.e2[k] = p2[k] - p0[k];
+    }
+    rec.idx[0] = i0;
+    rec.idx[1] = i1;
+    rec.idx[2] = i2;
+    records[(n - e) + (i - s)] = rec;
+}
+
+inline int blocksFor(long long n) { return (int)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+static_assert(sizeof(BuildNode) == sizeof(RtBuildNode), "host and device agree on the work table");
+
+#define RTB_HIP(call)                      \
+    do {                                   \
+        hipError_t e_ = (call);            \
+        if (e_ != hipSuccess) {            \
+            cleanup();                     \
+            return (int)e_;                \
+        }                                  \
+    } while (0)
+
+int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* streamPtr, int* degenerate) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(streamPtr);
+    const int n = job->triangleCnt, thr = job->threshold, tight = job->tightBounds;
+    *degenerate = 0;
+    float4 *bmin = nullptr, *bmax = nullptr;
+    uint32_t *orderA = nullptr, *orderB = nullptr, *cb = nullptr, *flags = nullptr;
+    uint64_t *keysA = nullptr, *keysB = nullptr;
+    unsigned char* axisOf = nullptr;
+    void* temp = nullptr;
+    BuildNode* nodes = nullptr;
+    auto cleanup = [&]() {
+        void* all[] = {bmin, bmax, orderA, orderB, cb, flags, keysA, keysB, axisOf, temp, nodes};
+        for (void* p : all)
+            if (p) (void)hipFree(p);
+    };
+    const size_t heap = (size_t)1 << (job->depth + 1);  // heap indices of all ranges, all levels
+    RTB_HIP(hipMalloc(&bmin, (size_t)n * sizeof(float4)));
+    RTB_HIP(hipMalloc(&bmax, (size_t)n * sizeof(float4)));
+    RTB_HIP(hipMalloc(&orderA, (size_t)n * 4));
+    RTB_HIP(hipMalloc(&orderB, (size_t)n * 4));
+    RTB_HIP(hipMalloc(&keysA, (size_t)n * 8));
+    RTB_HIP(hipMalloc(&keysB, (size_t)n * 8));
+    RTB_HIP(hipMalloc(&cb, heap * 6 * 4));
+    RTB_HIP(hipMalloc(&axisOf, heap));
+    RTB_HIP(hipMalloc(&flags, 4));
+    RTB_HIP(hipMalloc(&nodes, (size_t)job->nodeCnt * sizeof(BuildNode)));
+    RTB_HIP(hipMemsetAsync(flags, 0, 4, stream));
+    RTB_HIP(hipMemsetAsync(axisOf, 0, heap, stream));
+    RTB_HIP(hipMemcpyAsync(nodes, job->nodes, (size_t)job->nodeCnt * sizeof(BuildNode), hipMemcpyHostToDevice, stream));
+    size_t tempBytes = 0;
+    RTB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, keysA, keysB, orderA, orderB, n, 0, 64, stream));
+    RTB_HIP(hipMalloc(&temp, tempBytes));
+
+    const int grid = blocksFor(n);
+    hipLaunchKernelGGL(primBoundsKernel, dim3(grid), dim3(kBlock), 0, stream, n, job->devTriangles, job->devVertices, tight, bmin, bmax);
+    hipLaunchKernelGGL(iotaKernel, dim3(grid), dim3(kBlock), 0, stream, n, orderA);
+    for (int level = 0; level < job->depth; ++level) {
+        const uint32_t first = (1u << level) - 1u, count = 1u << level;
+        hipLaunchKernelGGL(boundsInitKernel, dim3(blocksFor(count)), dim3(kBlock), 0, stream, first, count, tight, cb);
+        hipLaunchKernelGGL(centroidBoundsKernel, dim3(grid), dim3(kBlock), 0, stream, n, thr, level, orderA, bmin, bmax, cb);
+        hipLaunchKernelGGL(sortKeyKernel, dim3(grid), dim3(kBlock), 0, stream, n, thr, level, orderA, bmin, bmax, cb, axisOf, keysA, flags);
+        // range ids of this level need level + 1 bits above the 32-bit coordinate
+        RTB_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, keysA, keysB, orderA, orderB, n, 0, 32 + level + 1, stream));
+        uint32_t* t = orderA;
+        orderA = orderB;
+        orderB = t;
+    }
+    float* recs = reinterpret_cast<float*>(job->devNodeRecords);
+    hipLaunchKernelGGL(leafBoxKernel, dim3(blocksFor(job->leafCnt)), dim3(kBlock), 0, stream, job->leafCnt, nodes, tight, orderA, bmin, bmax, recs);
+    // the table holds the leaves first, then the interior nodes by level, deepest first
+    int at = job->leafCnt;
+    for (int level = job->depth - 1; level >= 0; --level) {
+        const int cnt = job->interiorPerLevel[level];
+        if (cnt > 0) hipLaunchKernelGGL(interiorBoxKernel, dim3(blocksFor(cnt)), dim3(kBlock), 0, stream, cnt, nodes + at, axisOf, recs);
+        at += cnt;
+    }
+    hipLaunchKernelGGL(recordKernel, dim3(grid), dim3(kBlock), 0, stream, n, thr, orderA, job->devTriangles, job->devVertices,
+                       reinterpret_cast<TriRecord*>(job->devTriRecords));
+    uint32_t hostFlags = 0;
+    RTB_HIP(hipMemcpyAsync(&hostFlags, flags, 4, hipMemcpyDeviceToHost, stream));
+    RTB_HIP(hipStreamSynchronize(stream));
+    RTB_HIP(hipGetLastError());
+    *degenerate = (int)(hostFlags & 1u);
+    cleanup();
+    return 0;
+}

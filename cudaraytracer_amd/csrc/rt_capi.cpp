@@ -51,6 +51,12 @@ struct Workspace {
     size_t spillBytes = 0;
 };
 
+// How meshes without BVH nodes get theirs on the device (rt_set_device_bvh).
+struct BuildParams {
+    int threshold = 10;
+    int tightBounds = 1;
+};
+
 }  // namespace
 
 // One frame in flight: its own stream and workspace, so that consecutive frames can overlap.
@@ -75,6 +81,7 @@ struct rt_ctx {
     int ldsStack = RT_LDS_STACK_DEFAULT;  // traversal stack entries kept in LDS (older ones move to global memory)
     int maxWavesPerCu = 0;                // 0 = as many as are resident
     uint32_t sampleSeed = 1234;
+    BuildParams bvhBuild;  // for meshes that arrive without BVH nodes
     int tileOrderMode = RT_TILE_ORDER_CENTER_OUT;
     std::vector<int32_t> tileOrderHost;
     void* tileOrderDev = nullptr;
@@ -162,7 +169,8 @@ int treeDepth(const RtLinearNode* nodes, int nodeCnt, int primCnt, int* maxLeafP
 // `out` receives 32-byte records {bbmin, bbmax, ref, 0}; its size is 2 * (interior nodes + 1).
 // References are written relative to this tree (pair index / 2, primitive index within the
 // tree's primitive list) and made absolute by relocateRefs once the blob offsets are known.
-int pairLayout(const RtLinearNode* nodes, std::vector<RtLinearNode>& out, uint32_t leafTag, std::string* err) {
+int pairLayout(const RtLinearNode* nodes, std::vector<RtLinearNode>& out, uint32_t leafTag, std::string* err,
+               std::vector<int32_t>* recordOfNode = nullptr) {
     struct Item {
         int src, dst;
     };
@@ -198,6 +206,7 @@ int pairLayout(const RtLinearNode* nodes, std::vector<RtLinearNode>& out, uint32
         rec.axis = 0;
         rec.pad = 0;
         out[it.dst] = rec;
+        if (recordOfNode) (*recordOfNode)[it.src] = it.dst;
     }
     return RT_OK;
 }
@@ -229,8 +238,40 @@ int relocateRefs(std::vector<RtLinearNode>& recs, uint64_t unitBase, uint32_t pr
     return RT_OK;
 }
 
+// A mesh that arrives without BVH nodes gets its BVH on the device.  The tree's shape (median cuts down to
+// `threshold` primitives, csrc/host/BVH.h) follows from the count alone: this writes the depth-first node array
+// with references and leaf ranges but without boxes and axes, and the per-node facts the device build needs.
+struct StaticNodeInfo {
+    int32_t start, end, level;
+    uint32_t pathId;
+};
+struct DeviceBuild {
+    int mesh = 0;
+    RtBvhBuildJob job;
+    std::vector<RtBuildNode> table;
+    uint64_t offNodes = 0, offRecords = 0, offVertices = 0;
+};
+int staticTree(int n, int threshold, std::vector<RtLinearNode>& dfs, std::vector<StaticNodeInfo>& info, int s, int e, int level, uint32_t pathId) {
+    const int idx = (int)dfs.size();
+    dfs.push_back(RtLinearNode{});
+    info.push_back(StaticNodeInfo{s, e, level, pathId});
+    if (e - s <= threshold) {
+        // the host builder descends into the second half first, so ordered slots count from the far end
+        dfs[idx].offset = n - e;
+        dfs[idx].primCnt = (uint16_t)(e - s);
+    } else {
+        const int mid = (s + e) / 2;
+        staticTree(n, threshold, dfs, info, s, mid, level + 1, 2u * pathId);
+        const int second = staticTree(n, threshold, dfs, info, mid, e, level + 1, 2u * pathId + 1u);
+        dfs[idx].offset = second;
+        dfs[idx].primCnt = 0;
+    }
+    return idx;
+}
+
 // Flattens `desc` into a host blob.  Returns RT_OK or an error (message in *err).
-int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string* err) {
+int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string* err, const BuildParams* build = nullptr,
+              std::vector<DeviceBuild>* builds = nullptr) {
     auto bad = [&](const char* m) {
         *err = m;
         return RT_ERR_INVALID;
@@ -286,25 +327,61 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
         const RtMesh& m = d->meshes[mi];
         DevMesh& dm = meshes[mi];
         std::memset(&dm, 0, sizeof dm);
-        if (m.triangleCnt < 1 || !m.triangles || m.vertexCnt < 1 || !m.vertices || m.nodeCnt < 1 || !m.nodes)
-            return bad("mesh with missing triangles, vertices or nodes");
+        if (m.triangleCnt < 1 || !m.triangles || m.vertexCnt < 1 || !m.vertices) return bad("mesh with missing triangles or vertices");
+        const bool onDevice = m.nodeCnt == 0 && !m.nodes;
+        if (onDevice && !(build && builds)) return bad("mesh without BVH nodes: only rt_scene_upload can build them (on the device)");
+        if (!onDevice && (m.nodeCnt < 1 || !m.nodes)) return bad("mesh with an inconsistent node array");
         for (int t = 0; t < m.triangleCnt; ++t)
             for (int k = 0; k < 3; ++k)
                 if (m.triangles[t].i[k] < 0 || m.triangles[t].i[k] >= m.vertexCnt) return bad("triangle vertex index out of range");
-        int depth = treeDepth(m.nodes, m.nodeCnt, m.triangleCnt, nullptr, err);
-        if (depth < 0) return RT_ERR_INVALID;
+        std::vector<RtLinearNode> staticNodes;
+        std::vector<StaticNodeInfo> staticInfo;
+        std::vector<int32_t> recordOfNode;
+        int depth;
+        if (onDevice) {
+            staticTree(m.triangleCnt, build->threshold, staticNodes, staticInfo, 0, m.triangleCnt, 0, 1u);
+            depth = 0;
+            for (const StaticNodeInfo& si : staticInfo) depth = std::max(depth, (int)si.level);
+            recordOfNode.assign(staticNodes.size(), -1);
+        } else {
+            depth = treeDepth(m.nodes, m.nodeCnt, m.triangleCnt, nullptr, err);
+            if (depth < 0) return RT_ERR_INVALID;
+        }
         hd.maxMeshDepth = std::max(hd.maxMeshDepth, depth);
         std::memcpy(dm.inv, m.transformInverse, sizeof dm.inv);
         dm.triangleCnt = m.triangleCnt;
-        dm.nodeCnt = m.nodeCnt;
+        dm.nodeCnt = onDevice ? (int)staticNodes.size() : m.nodeCnt;
         dm.vertexCnt = m.vertexCnt;
-        if (int r = pairLayout(m.nodes, meshPairs[mi], 0u, err)) return r;
+        if (int r = pairLayout(onDevice ? staticNodes.data() : m.nodes, meshPairs[mi], 0u, err, onDevice ? &recordOfNode : nullptr)) return r;
         dm.offNodes = reserve(meshPairs[mi].size() * sizeof(RtLinearNode));
         dm.recordBase = recordBase;
         dm.offTriRecords = hd.offRecords + (uint64_t)recordBase * sizeof(TriRecord);
         if (int r = relocateRefs(meshPairs[mi], dm.offNodes / 64, recordBase, err)) return r;
         dm.rootRef = (RT_REF_ROOT_AXIS << 29) | (uint32_t)(dm.offNodes / 64);
         recordBase += (uint32_t)m.triangleCnt;
+        if (onDevice) {
+            builds->emplace_back();
+            DeviceBuild& b = builds->back();
+            b.mesh = mi;
+            std::memset(&b.job, 0, sizeof b.job);
+            b.job.triangleCnt = m.triangleCnt;
+            b.job.threshold = build->threshold;
+            b.job.tightBounds = build->tightBounds;
+            b.job.depth = depth;
+            // leaves first, then interior nodes by level, deepest level first
+            for (size_t k = 0; k < staticNodes.size(); ++k)
+                if (staticNodes[k].primCnt > 0)
+                    b.table.push_back(RtBuildNode{staticInfo[k].start, staticInfo[k].end, recordOfNode[k], -1, -1, staticInfo[k].pathId});
+            b.job.leafCnt = (int32_t)b.table.size();
+            for (int level = depth - 1; level >= 0; --level)
+                for (size_t k = 0; k < staticNodes.size(); ++k)
+                    if (staticNodes[k].primCnt == 0 && staticInfo[k].level == level) {
+                        b.table.push_back(RtBuildNode{staticInfo[k].start, staticInfo[k].end, recordOfNode[k], recordOfNode[k + 1],
+                                                      recordOfNode[staticNodes[k].offset], staticInfo[k].pathId});
+                        b.job.interiorPerLevel[level]++;
+                    }
+            b.job.nodeCnt = (int32_t)b.table.size();
+        }
         dm.offVertices = reserve((size_t)m.vertexCnt * sizeof(RtVertex));
         const RtTexture* tex[3] = {&m.diffuse, &m.normals, &m.specular};
         for (int k = 0; k < 3; ++k) {
@@ -350,7 +427,8 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
         std::memcpy(base + dm.offNodes, meshPairs[mi].data(), meshPairs[mi].size() * sizeof(RtLinearNode));
         std::memcpy(base + dm.offVertices, m.vertices, (size_t)m.vertexCnt * sizeof(RtVertex));
         TriRecord* rec = reinterpret_cast<TriRecord*>(base + dm.offTriRecords);
-        for (int t = 0; t < m.triangleCnt; ++t) {
+        const bool onDevice = m.nodeCnt == 0 && !m.nodes;  // the device build writes this mesh's records
+        for (int t = 0; !onDevice && t < m.triangleCnt; ++t) {
             const float* p0 = m.vertices[m.triangles[t].i[0]].position;
             const float* p1 = m.vertices[m.triangles[t].i[1]].position;
             const float* p2 = m.vertices[m.triangles[t].i[2]].position;
@@ -366,6 +444,12 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
             std::memcpy(base + dm.offTex[k], tex[k]->data, (size_t)tex[k]->width * tex[k]->height * 4);
     }
     if (d->meshCnt) std::memcpy(base + hd.offMeshes, meshes.data(), meshes.size() * sizeof(DevMesh));
+    if (builds)
+        for (DeviceBuild& b : *builds) {
+            b.offNodes = meshes[b.mesh].offNodes;
+            b.offRecords = meshes[b.mesh].offTriRecords;
+            b.offVertices = meshes[b.mesh].offVertices;
+        }
     std::memcpy(base, &hd, sizeof hd);
     return RT_OK;
 }
@@ -586,7 +670,8 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
     if (!ctx) return nullptr;
     std::vector<unsigned char> host;
     std::string err;
-    int r = packScene(desc, host, &err);
+    std::vector<DeviceBuild> builds;
+    int r = packScene(desc, host, &err, &ctx->bvhBuild, &builds);
     if (r != RT_OK) {
         fail(ctx, r, "%s", err.c_str());
         return nullptr;
@@ -600,6 +685,31 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
         if (dev) hipFree(dev);
         return nullptr;
     }
+    // meshes that came without BVH nodes: order their triangles and fill boxes, axes and records on the device
+    for (DeviceBuild& b : builds) {
+        const RtMesh& m = desc->meshes[b.mesh];
+        int32_t* devTris = nullptr;
+        e = hipMalloc((void**)&devTris, (size_t)m.triangleCnt * sizeof(RtTriangle));
+        if (e == hipSuccess) e = hipMemcpy(devTris, m.triangles, (size_t)m.triangleCnt * sizeof(RtTriangle), hipMemcpyHostToDevice);
+        int degenerate = 0;
+        if (e == hipSuccess) {
+            b.job.nodes = b.table.data();
+            b.job.devTriangles = devTris;
+            b.job.devVertices = dev + b.offVertices;
+            b.job.devNodeRecords = dev + b.offNodes;
+            b.job.devTriRecords = dev + b.offRecords;
+            e = (hipError_t)rtk_build_mesh_bvh(&b.job, ctx->stream, &degenerate);
+        }
+        if (devTris) hipFree(devTris);
+        if (e != hipSuccess || degenerate) {
+            if (e != hipSuccess)
+                fail(ctx, RT_ERR_DEVICE, "BVH build of mesh %d on the device: %s", b.mesh, hipGetErrorString(e));
+            else
+                fail(ctx, RT_ERR_INVALID, "mesh %d has a range of triangles whose box centroids all coincide; build its BVH on the host", b.mesh);
+            hipFree(dev);
+            return nullptr;
+        }
+    }
     rt_scene* sc = new rt_scene();
     sc->ctx = ctx;
     sc->blob = dev;
@@ -607,6 +717,14 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
     sc->bytes = host.size();
     std::memcpy(&sc->header, host.data(), sizeof(BlobHeader));
     return sc;
+}
+
+int rt_set_device_bvh(rt_ctx* ctx, int threshold, int tightBounds) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (threshold < 1 || threshold > RT_REF_MAX_LEAF_PRIMS) return fail(ctx, RT_ERR_INVALID, "leaf threshold must be in 1..%d", RT_REF_MAX_LEAF_PRIMS);
+    ctx->bvhBuild.threshold = threshold;
+    ctx->bvhBuild.tightBounds = tightBounds ? 1 : 0;
+    return RT_OK;
 }
 
 rt_scene* rt_scene_adopt_blob(rt_ctx* ctx, const void* devBlob, size_t bytes) {

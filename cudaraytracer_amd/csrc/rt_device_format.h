@@ -197,6 +197,32 @@ struct FrameParams {
 // `stageEvents`: optional hipEvent_t[5] recorded at frame start, after the level-0 closest-hit
 // trace, after shading, after the shadow trace, at frame end.  Returns a hipError_t value.
 int rtk_render_frame(const FrameParams* frame, int hasSecondary, int count, int cuCount, void* stream, void** stageEvents);
+// ---- mesh BVH construction on the device (kernels/rt_bvh_build.hip) -------------
+// The tree's shape follows from the primitive count alone (median cuts), so the host writes the
+// node records' references and this work table; the device orders the primitives and fills in
+// boxes, split axes and triangle records.
+struct RtBuildNode {
+    int32_t start, end;   // primitive positions of the node's range
+    int32_t rec;          // index of the node's 32-byte record in the mesh's node array
+    int32_t left, right;  // records of the children (-1 for a leaf)
+    uint32_t pathId;      // heap index of the range (root 1, children 2i and 2i + 1)
+};
+struct RtBvhBuildJob {
+    int32_t triangleCnt, threshold, tightBounds;
+    int32_t depth;     // levels of cuts = depth of the deepest leaf
+    int32_t nodeCnt;   // entries of `nodes`: leafCnt leaves first, then interior nodes by level, deepest level first
+    int32_t leafCnt;
+    int32_t interiorPerLevel[RT_STACK_ENTRIES];
+    const RtBuildNode* nodes;           // host
+    const int32_t* devTriangles;        // [3 * triangleCnt] vertex indices, caller's order
+    const unsigned char* devVertices;   // RtVertex array
+    unsigned char* devNodeRecords;      // the mesh's node records (references already in place)
+    unsigned char* devTriRecords;       // the mesh's triangle records
+};
+// Runs the build on `stream` and waits for it.  Returns a hipError_t value; *degenerate is set when a range's
+// centroids all coincide (the reference makes such a range one big leaf; build that mesh on the host).
+int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* stream, int* degenerate);
+
 // Resident wavefronts per CU of the trace kernels for a given LDS stack size.
 int rtk_trace_waves_per_cu(int stackLds);
 

@@ -302,6 +302,17 @@ int rt_timing_read_stages(rt_ctx* ctx, double* totalMs, double* stageMs, int* la
  * A frame that needs more reports RT_ERR_LIMIT from rt_sync. */
 int rt_set_path_budget(rt_ctx* ctx, int nodesPerPixel);
 
+/* Mesh BVHs built on the device.  A mesh handed to rt_scene_upload with nodes == NULL and nodeCnt == 0 gets its
+ * BVH built on the GPU with the algorithm of cudaTracer/BVH.h:104-181 (median cut of the box centroids along the
+ * widest axis of the centroid bounds, leaves of at most `threshold` triangles; the reference uses 10,
+ * cudaTracer/CudaMesh.h:58): same tree shape, boxes and split axes as the host builder whenever the median
+ * centroids are distinct; the order of triangles inside a leaf may differ.  `tightBounds` = 0 starts boxes from
+ * the reference's (FLT_MAX, FLT_MIN) empty box (cudaTracer/BoundingBox.cuh:25-27), 1 from a true empty box.
+ * The triangles of such a mesh are given in any order; rt_scene_pack (host only) rejects it.  A mesh in which
+ * some range of triangles has coinciding box centroids is rejected with RT_ERR_INVALID (the reference turns such
+ * a range into one leaf of any size); build that mesh's BVH on the host.  Defaults: threshold 10, tight bounds. */
+int rt_set_device_bvh(rt_ctx* ctx, int threshold, int tightBounds);
+
 /* Seed of the sub-pixel jitter used with samples > 1 (default 1234, the seed the reference gives curand,
  * cudaTracer/Main.cu:127).  Change it per frame to accumulate independent samples over frames. */
 int rt_set_sample_seed(rt_ctx* ctx, uint32_t seed);

@@ -177,3 +177,11 @@ def test_chain_deeper_than_the_traversal_stack_is_a_limit_error(rtlib):
     m.nodes, m.nodeCnt = C.cast(nodes, C.POINTER(N.RtLinearNode)), cnt
     expect_error(rtlib, s.desc, RT_ERR_LIMIT, "too deep")
     m.nodes, m.nodeCnt = keep
+
+
+def test_host_only_packing_rejects_a_mesh_without_nodes(rtlib):
+    """Meshes without BVH nodes are for rt_scene_upload, which builds their BVH on the device."""
+    s = rt.HostScene("soup", 32, 32, 500, 1, 0, tight_bvh=True, device_bvh=True)
+    m = s.desc.contents.meshes[0]
+    assert m.nodeCnt == 0 and not m.nodes
+    expect_error(rtlib, s.desc, RT_ERR_INVALID, "without BVH nodes")

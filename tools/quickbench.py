@@ -24,10 +24,11 @@ ap.add_argument("--lds-stack", type=int, default=0)
 ap.add_argument("--frames-in-flight", type=int, default=0)
 ap.add_argument("--waves", type=int, default=0)
 ap.add_argument("--tile-order", type=int, default=-1)
+ap.add_argument("--device-bvh", action="store_true")
 a = ap.parse_args()
 
 t = time.time()
-scene = rt.HostScene(a.scene, a.width, a.height, a.size, a.lights, a.max_depth, tight_bvh=not a.reference_bvh)
+scene = rt.HostScene(a.scene, a.width, a.height, a.size, a.lights, a.max_depth, tight_bvh=not a.reference_bvh, device_bvh=a.device_bvh)
 print(f"scene {a.scene} size {a.size}: built in {time.time()-t:.2f}s, depth {scene.bvh_depth()}", flush=True)
 with rt.Context(0) as ctx:
     if a.waves:
@@ -38,7 +39,17 @@ with rt.Context(0) as ctx:
         ctx.set_frames_in_flight(a.frames_in_flight)
     if a.lds_stack:
         ctx.set_lds_stack(a.lds_stack)
+    ctx.set_device_bvh(10, not a.reference_bvh)
+    ctx.sync()
+    t = time.time()
     ds = ctx.upload(scene)
+    ctx.sync()
+    print(f"upload{' + device BVH build' if a.device_bvh else ''}: {time.time()-t:.3f}s", flush=True)
+    t = time.time()
+    ds2 = ctx.upload(scene)
+    ctx.sync()
+    print(f"second upload: {time.time()-t:.3f}s", flush=True)
+    ctx.free_scene(ds2)
     surf, pitch = ctx.surface(a.width, a.height)
     cnt = ctx.alloc(rt.RT_COUNTER_CNT * 8)
     ctx.render(ds, scene.opts, scene.camera, surf, pitch, None, cnt)
