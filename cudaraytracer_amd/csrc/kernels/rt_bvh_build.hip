@@ -111,18 +111,47 @@ __device__ __forceinline__ void centroidOf(const float4 lo, const float4 hi, flo
 __global__ void __launch_bounds__(kBlock) centroidBoundsKernel(int n, int threshold, int level, const uint32_t* __restrict__ order,
                                                                const float4* __restrict__ bmin, const float4* __restrict__ bmax, uint32_t* cb) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    int s, e;
-    uint32_t id;
-    if (!descend(i, n, threshold, level, s, e, id)) return;
-    const uint32_t prim = order[i];
-    float c[3];
-    centroidOf(bmin[prim], bmax[prim], c);
-    uint32_t* b = cb + 6 * (size_t)(id - 1u);
-    for (int a = 0; a < 3; ++a) {
-        const uint32_t v = orderedBits(c[a]);
-        atomicMin(b + a, v);
-        atomicMax(b + 3 + a, v);
+    int s = 0, e = 0;
+    uint32_t id = 0;
+    const bool active = i < n && descend(i, n, threshold, level, s, e, id);
+    uint32_t lo[3], hi[3];
+    if (active) {
+        const uint32_t prim = order[i];
+        float c[3];
+        centroidOf(bmin[prim], bmax[prim], c);
+        for (int a = 0; a < 3; ++a) lo[a] = hi[a] = orderedBits(c[a]);
+    } else {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = 0xffffffffu;
+            hi[a] = 0u;
+        }
+    }
+    // Ranges are runs of consecutive positions, so near the root a whole wavefront sits in one range: reduce
+    // there first and let one lane touch memory, instead of 64 atomics on the same six words.
+    const unsigned long long act = __ballot(active);
+    if (act == 0ull) return;
+    const uint32_t firstId = __shfl(id, __ffsll((long long)act) - 1, 64);
+    const bool uniform = __ballot(active && id != firstId) == 0ull;
+    if (uniform) {
+        for (int off = 32; off > 0; off >>= 1)
+            for (int a = 0; a < 3; ++a) {
+                const uint32_t l = __shfl_xor(lo[a], off, 64), h = __shfl_xor(hi[a], off, 64);
+                lo[a] = l < lo[a] ? l : lo[a];
+                hi[a] = h > hi[a] ? h : hi[a];
+            }
+        if ((threadIdx.x & 63) == 0) {
+            uint32_t* b = cb + 6 * (size_t)(firstId - 1u);
+            for (int a = 0; a < 3; ++a) {
+                atomicMin(b + a, lo[a]);
+                atomicMax(b + 3 + a, hi[a]);
+            }
+        }
+    } else if (active) {
+        uint32_t* b = cb + 6 * (size_t)(id - 1u);
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(b + a, lo[a]);
+            atomicMax(b + 3 + a, hi[a]);
+        }
     }
 }
 

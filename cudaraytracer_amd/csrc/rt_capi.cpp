@@ -6,6 +6,7 @@
 #include <hip/hip_vector_types.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -671,7 +672,11 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
     std::vector<unsigned char> host;
     std::string err;
     std::vector<DeviceBuild> builds;
+    const bool verbose = std::getenv("RT_TRACE_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
     int r = packScene(desc, host, &err, &ctx->bvhBuild, &builds);
+    if (verbose) std::fprintf(stderr, "rt_scene_upload: packed %zu bytes in %.3f s\n", host.size(), now() - t0);
     if (r != RT_OK) {
         fail(ctx, r, "%s", err.c_str());
         return nullptr;
@@ -698,7 +703,9 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
             b.job.devVertices = dev + b.offVertices;
             b.job.devNodeRecords = dev + b.offNodes;
             b.job.devTriRecords = dev + b.offRecords;
+            t0 = now();
             e = (hipError_t)rtk_build_mesh_bvh(&b.job, ctx->stream, &degenerate);
+            if (verbose) std::fprintf(stderr, "rt_scene_upload: BVH of mesh %d (%d triangles) built on the device in %.3f s\n", b.mesh, m.triangleCnt, now() - t0);
         }
         if (devTris) hipFree(devTris);
         if (e != hipSuccess || degenerate) {
