@@ -127,6 +127,7 @@ HARNESS = {
     "rth_scene_bvh_depth": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rth_scene_rotate_lights": (None, [C.c_void_p, C.c_float]),
     "rth_scene_set_camera": (None, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "rth_scene_run_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_char_p, C.c_void_p]),
     "rth_write_png": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
     "rth_floats_to_bytes": (None, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "rth_read_png": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

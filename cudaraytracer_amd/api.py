@@ -69,6 +69,14 @@ class HostScene:
         self.lib.rth_scene_bvh_depth(self.h, C.byref(a), C.byref(b))
         return a.value, b.value
 
+    def run_frames(self, frames, dt, png_path=None, device=0):
+        """The C++ RayTracer driver end to end: upload, `frames` x (rotate lights by dt, render), dump; returns the last frame."""
+        rgba = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        rc = self.lib.rth_scene_run_frames(self.h, device, frames, dt, png_path.encode() if png_path else None, rgba.ctypes.data)
+        if rc != 0:
+            raise RtError(self.lib.rth_last_error().decode())
+        return rgba
+
     def rotate_lights(self, dt):
         self.lib.rth_scene_rotate_lights(self.h, dt)
 

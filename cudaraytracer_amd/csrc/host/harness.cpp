@@ -363,6 +363,34 @@ void rth_scene_set_camera(rth_scene* h, const float pos[3], const float dir[3]) 
 }
 
 // PicDumper: float RGBA -> 8-bit (x256, clamped) -> PNG.
+// The headless frame loop of the reference's RayTracer (cudaTracer/RayTracer.cpp:188-208) on the C++ driver:
+// upload, `frames` times { rotate the lights by dt, set them, render, wait }, then dump the last frame as PNG
+// (PicDumper) and, if `rgba` is given, copy its float pixels out.  The scene's light table keeps the rotation.
+int rth_scene_run_frames(rth_scene* h, int device, int frames, float dt, const char* pngPath, float* rgba) {
+    rt_ctx* ctx = rt_create(device);
+    if (!ctx) {
+        g_error = rt_last_error(nullptr);
+        return -1;
+    }
+    int rc = 0;
+    try {
+        h->rt->upload(ctx);
+        for (int i = 0; i < frames; ++i) h->rt->update(dt);
+        if (rgba) {
+            const std::vector<float> px = h->rt->readFrame();
+            std::memcpy(rgba, px.data(), px.size() * sizeof(float));
+        }
+        if (pngPath && !h->rt->dumpFrame(pngPath)) throw std::runtime_error("cannot write the PNG");
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        rc = -1;
+    }
+    h->rt->release();
+    rt_destroy(ctx);
+    h->refresh();
+    return rc;
+}
+
 int rth_write_png(const char* path, const float* rgba, int width, int height) {
     std::vector<float> px(rgba, rgba + (size_t)width * height * 4);
     return PicDumper(width, height).toDisk(px, path) ? 0 : -1;

@@ -321,3 +321,23 @@ def test_full_size_soup_properties(gpu_ctx, oracle):
         assert np.array_equal(again[1], keys) and np.array_equal(again[0], rgba, equal_nan=True)
     finally:
         gpu_ctx.free_scene(dscene)
+
+
+def test_cpp_driver_frame_loop_and_png_dump(oracle, tmp_path):
+    """RayTracer.h (the C++ mirror of cudaTracer/RayTracer.cpp) drives three frames with moving lights through the
+    C-ABI and dumps the last one; the oracle renders the same final state."""
+    from PIL import Image
+
+    from parity import to_8bit
+
+    w, h = 96, 64
+    scene = rt.HostScene("mixed", w, h, 0, 3, 2)
+    png = tmp_path / "frame.png"
+    rgba = scene.run_frames(3, 0.4, str(png))
+    ref_rgba, ref_keys, _ = oracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=8)  # lights as after 3 rotations
+    assert_parity(rgba, None, ref_rgba, None)
+    other = rt.HostScene("mixed", w, h, 0, 3, 2)
+    still = oracle.render(other.desc, other.opts, other.camera, w, h, threads=8)[0]
+    assert not np.array_equal(still, ref_rgba)  # the lights did move
+    dumped = np.asarray(Image.open(png).convert("RGBA")).astype(np.int32)
+    assert np.abs(dumped - to_8bit(ref_rgba)).max() <= 1
