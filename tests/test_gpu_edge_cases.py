@@ -1,0 +1,144 @@
+"""Edge cases of the render path: no lights, spheres only (no mesh at all), tiny and odd frame sizes, an empty
+tile shard, deep recursion between two mirrors."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cudaraytracer_amd as rt
+from cudaraytracer_amd import _native as N
+from parity import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+
+class SphereScene:
+    """A scene description assembled by hand: spheres in one scene-BVH leaf (or scanned linearly), no meshes."""
+
+    def __init__(self, w, h, spheres, lights, max_depth=0):
+        n = len(spheres)
+        self.shapes = (N.RtShape * n)()
+        lo = np.full(3, np.finfo(np.float32).max, dtype=np.float32)
+        hi = np.full(3, -np.finfo(np.float32).max, dtype=np.float32)
+        for i, (c, r, mat, ior) in enumerate(spheres):
+            s = self.shapes[i]
+            s.kind = 0  # RT_SHAPE_SPHERE
+            s.center[:] = c
+            s.radius, s.radius2 = r, float(np.float32(r) * np.float32(r))
+            s.meshIdx = -1
+            s.material.materialType = mat
+            s.material.ior, s.material.Kd, s.material.Ks, s.material.specularExponent = ior, 0.8, 0.2, 25.0
+            s.material.diffuseColor[:] = [0.2 + 0.1 * i, 0.5, 0.9 - 0.1 * i]
+            b0 = np.float32(c) - np.float32(r)
+            b1 = np.float32(c) + np.float32(r)
+            s.bbmin[:] = b0.tolist()
+            s.bbmax[:] = b1.tolist()
+            s.tag = i
+            lo, hi = np.minimum(lo, b0), np.maximum(hi, b1)
+        self.nodes = (N.RtLinearNode * 1)()
+        self.nodes[0].bbmin[:] = lo.tolist()
+        self.nodes[0].bbmax[:] = hi.tolist()
+        self.nodes[0].offset, self.nodes[0].primCnt = 0, n
+        self.lights = (N.RtLight * max(len(lights), 1))()
+        for i, (p, power) in enumerate(lights):
+            self.lights[i].position[:] = p
+            self.lights[i].intensity[:] = [0.5, 0.4, 0.3]
+            self.lights[i].power = power
+        self.desc = N.RtSceneDesc(self.lights if lights else None, len(lights), self.shapes, n, None, 0, self.nodes, 1)
+        self.opts = N.RtDeviceOpts()
+        o = self.opts
+        o.imageAspectRatio, o.scale = w / h, 1.0
+        o.width, o.height = w, h
+        o.backgroundColor[:] = [0.2, 0.7, 0.8]
+        o.shadowBias, o.blockSize, o.maxDepth, o.samples = 1e-4, 4, max_depth, 1
+        o.gammaCorrection, o.useSceneBvh, o.useMeshBvhs = 1, 1, 1
+        self.camera = N.RtCamera()
+        self.camera.orig[:] = [0, 0, 0]
+        self.camera.camera[:] = np.eye(4, dtype=np.float32).ravel().tolist()
+        self.width, self.height = w, h
+
+
+def render_both(ctx, oracle, scene):
+    w, h = scene.width, scene.height
+    ref = oracle.render(C.pointer(scene.desc), C.pointer(scene.opts), C.pointer(scene.camera), w, h, threads=4, shadow_any_hit=True)
+    dscene = ctx.upload(C.pointer(scene.desc))
+    surf, pitch = ctx.surface(w, h)
+    keys = ctx.alloc(w * h * 16)
+    cnt = ctx.alloc(rt.RT_COUNTER_CNT * 8)
+    try:
+        ctx.render(dscene, scene.opts, C.pointer(scene.camera), surf, pitch, keys, cnt)
+        ctx.sync()
+        rgba = ctx.download_surface(surf, pitch, w, h)
+        k = ctx.download(keys, (h, w, 4), np.int32)
+        raw = ctx.download(cnt, (rt.RT_COUNTER_CNT,), np.uint64)
+    finally:
+        ctx.free(surf)
+        ctx.free(keys)
+        ctx.free(cnt)
+        ctx.free_scene(dscene)
+    got_cnt = {name: int(raw[i]) for i, name in enumerate(rt.RT_COUNTER_NAMES)}
+    assert_parity(rgba, k, ref[0], ref[1])
+    assert got_cnt == ref[2], (got_cnt, ref[2])
+    return rgba, k, got_cnt
+
+
+SPHERES = [([0.0, 0.0, 6.0], 1.5, 0, 1.3), ([2.5, 0.5, 5.0], 1.0, 1, 64.0), ([-2.2, -0.3, 4.5], 1.0, 2, 1.5), ([0.0, -101.0, 6.0], 100.0, 0, 1.3)]
+LIGHTS = [([5.0, 8.0, 0.0], 20.0), ([-6.0, 4.0, 3.0], 12.0)]
+
+
+@pytest.mark.parametrize("w,h", [(96, 64), (1, 1), (7, 3), (9, 130)])
+def test_spheres_only_scene(gpu_ctx, oracle, w, h):
+    """No mesh in the scene at all: diffuse, mirror and glass spheres over a ground sphere."""
+    rgba, keys, cnt = render_both(gpu_ctx, oracle, SphereScene(w, h, SPHERES, LIGHTS, max_depth=4))
+    assert cnt["tri"] == 0 and cnt["mesh_entry"] == 0 and cnt["sphere"] > 0
+    if w >= 96:
+        assert cnt["secondary"] > 0 and set(np.unique(keys[..., 0]).tolist()) >= {0, 1, 2, 3}
+
+
+def test_scene_without_lights(gpu_ctx, oracle):
+    """Diffuse surfaces come out black (tracer.cu:169-200 sums over zero lights), mirrors still reflect the background."""
+    rgba, keys, cnt = render_both(gpu_ctx, oracle, SphereScene(80, 60, SPHERES, [], max_depth=2))
+    assert cnt["shadow"] == 0
+    diffuse = keys[..., 0] == 0
+    assert diffuse.any() and np.all(rgba[diffuse][:, :3] == 0.0)
+
+
+def test_linear_scan_over_spheres(gpu_ctx, oracle):
+    s = SphereScene(64, 48, SPHERES, LIGHTS, max_depth=3)
+    s.opts.useSceneBvh = 0
+    rgba, keys, cnt = render_both(gpu_ctx, oracle, s)
+    assert cnt["node"] == 0
+
+
+def test_two_mirrors_to_the_depth_limit(gpu_ctx, oracle):
+    """Rays bounce between two large mirror spheres until maxDepth cuts them off (tracer.cu:16)."""
+    mirrors = [([-3.0, 0.0, 6.0], 2.9, 1, 64.0), ([3.0, 0.0, 6.0], 2.9, 1, 64.0)]
+    gpu_ctx.set_path_budget(17)  # a mirror path is a chain of up to maxDepth + 1 nodes per pixel
+    try:
+        rgba, keys, cnt = render_both(gpu_ctx, oracle, SphereScene(64, 40, mirrors, LIGHTS, max_depth=15))
+    finally:
+        gpu_ctx.set_path_budget(3)
+    assert cnt["secondary"] > cnt["primary"] * 0.2
+
+
+def test_empty_and_single_tile_shards(gpu_ctx):
+    """A 16x8 frame has two tiles: with a stride of 5, shards 2..4 are empty and must leave everything untouched."""
+    s = SphereScene(16, 8, SPHERES, LIGHTS, max_depth=1)
+    dscene = gpu_ctx.upload(C.pointer(s.desc))
+    surf, pitch = gpu_ctx.surface(16, 8)
+    try:
+        gpu_ctx.render(dscene, s.opts, C.pointer(s.camera), surf, pitch)
+        gpu_ctx.sync()
+        full = gpu_ctx.download_surface(surf, pitch, 16, 8)
+        gpu_ctx.zero(surf, pitch * 8)
+        for first in (4, 2, 3):
+            gpu_ctx.render(dscene, s.opts, C.pointer(s.camera), surf, pitch, None, None, first, 5)
+        gpu_ctx.sync()
+        assert np.all(gpu_ctx.download_surface(surf, pitch, 16, 8) == 0.0)
+        for first in (1, 0):
+            gpu_ctx.render(dscene, s.opts, C.pointer(s.camera), surf, pitch, None, None, first, 5)
+        gpu_ctx.sync()
+        assert np.array_equal(gpu_ctx.download_surface(surf, pitch, 16, 8), full, equal_nan=True)
+    finally:
+        gpu_ctx.free(surf)
+        gpu_ctx.free_scene(dscene)
