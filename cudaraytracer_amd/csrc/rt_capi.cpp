@@ -89,6 +89,10 @@ struct rt_ctx {
     size_t tileOrderCap = 0;
     long long tileOrderKey[6] = {-1, -1, -1, -1, -1, -1};
     int wavesPerCu = 0, wavesForLds = -1;
+    // pinned staging for rt_surface_download: two chunks, so that the copy from the device overlaps the copy to the caller
+    void* staging[2] = {nullptr, nullptr};
+    hipEvent_t stagingDone[2] = {nullptr, nullptr};
+    hipStream_t copyStream = nullptr;
     std::string error;
     std::vector<TimedLaunch> launches;  // events of launches since the last reset
     size_t launchesUsed = 0;
@@ -567,6 +571,11 @@ void rt_destroy(rt_ctx* ctx) {
         if (sl.done) hipEventDestroy(sl.done);
     }
     if (ctx->tileOrderDev) hipFree(ctx->tileOrderDev);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->staging[k]) hipHostFree(ctx->staging[k]);
+        if (ctx->stagingDone[k]) hipEventDestroy(ctx->stagingDone[k]);
+    }
+    if (ctx->copyStream) hipStreamDestroy(ctx->copyStream);
     hipStreamDestroy(ctx->ownStream);
     delete ctx;
 }
@@ -801,10 +810,39 @@ int rt_surface_create(rt_ctx* ctx, int width, int height, void** devSurface, siz
 
 int rt_surface_download(rt_ctx* ctx, const void* devSurface, size_t pitch, int width, int height, float* hostRgba) {
     if (!ctx) return RT_ERR_INVALID;
-    if (!devSurface || !hostRgba || pitch < (size_t)width * 16) return fail(ctx, RT_ERR_INVALID, "bad download arguments");
+    if (!devSurface || !hostRgba || width < 1 || height < 1 || pitch < (size_t)width * 16) return fail(ctx, RT_ERR_INVALID, "bad download arguments");
     if (int r = bind(ctx)) return r;
     if (int r = syncFrames(ctx)) return r;
-    RT_HIP(ctx, hipMemcpy2D(hostRgba, (size_t)width * 16, devSurface, pitch, (size_t)width * 16, height, hipMemcpyDeviceToHost));
+    // The caller's buffer is ordinary pageable memory, which the copy engine cannot reach directly: rows travel in
+    // chunks through two pinned buffers, the next chunk leaving the device while the previous one is copied out.
+    constexpr size_t kChunk = 4u << 20;
+    if (!ctx->copyStream) {
+        RT_HIP(ctx, hipStreamCreateWithFlags(&ctx->copyStream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            RT_HIP(ctx, hipHostMalloc(&ctx->staging[k], kChunk, hipHostMallocDefault));
+            RT_HIP(ctx, hipEventCreateWithFlags(&ctx->stagingDone[k], hipEventDisableTiming));
+        }
+    }
+    const size_t rowBytes = (size_t)width * 16;
+    if (rowBytes > kChunk) {  // a single row larger than a chunk: plain copy
+        RT_HIP(ctx, hipMemcpy2D(hostRgba, rowBytes, devSurface, pitch, rowBytes, height, hipMemcpyDeviceToHost));
+        return RT_OK;
+    }
+    const int rowsPerChunk = (int)(kChunk / rowBytes);
+    const int chunks = (height + rowsPerChunk - 1) / rowsPerChunk;
+    auto rowsOf = [&](int c) { return std::min(rowsPerChunk, height - c * rowsPerChunk); };
+    for (int c = 0; c <= chunks; ++c) {
+        if (c < chunks) {
+            const unsigned char* src = static_cast<const unsigned char*>(devSurface) + (size_t)c * rowsPerChunk * pitch;
+            RT_HIP(ctx, hipMemcpy2DAsync(ctx->staging[c & 1], rowBytes, src, pitch, rowBytes, rowsOf(c), hipMemcpyDeviceToHost, ctx->copyStream));
+            RT_HIP(ctx, hipEventRecord(ctx->stagingDone[c & 1], ctx->copyStream));
+        }
+        if (c > 0) {
+            const int p = c - 1;
+            RT_HIP(ctx, hipEventSynchronize(ctx->stagingDone[p & 1]));
+            std::memcpy(reinterpret_cast<unsigned char*>(hostRgba) + (size_t)p * rowsPerChunk * rowBytes, ctx->staging[p & 1], (size_t)rowsOf(p) * rowBytes);
+        }
+    }
     return RT_OK;
 }
 
