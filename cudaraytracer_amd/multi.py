@@ -8,7 +8,7 @@ whole surface); the tile of this module is the reference's thread block made
 across GPUs without a work queue between them.
 
 The only collectives are the one-off scene broadcast and the per-frame gather
-of finished tiles (point-to-point sends to rank 0: every peer has its own xGMI
+of finished tiles (batched point-to-point sends to rank 0: every peer has its own xGMI
 link to GPU 0, so the N-1 transfers run in parallel).  The functions work on
 any torch.distributed backend: "nccl" (RCCL) with device tensors in production,
 "gloo" with host tensors in the CPU tests.
@@ -86,10 +86,15 @@ class TileGather:
     def gather(self, surface):
         """Every rank passes its own surface (only its tiles are read).  Rank 0 returns the assembled [h, w, c] frame."""
         mine = self.tiles(surface)
+        # Both sides use the batched point-to-point call: on RCCL it puts rank 0's N-1 receives into ONE group, so
+        # they run concurrently over the peers' separate xGMI links, and it keeps sender and receiver on the same
+        # communicator.
         if self.rank != 0:
-            dist.send(mine, dst=0)
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, 0)]):
+                q.wait()
             return None
-        reqs = [dist.irecv(self.buf[r, :tile_count(self.w, self.h, r, self.world)], src=r) for r in range(1, self.world)]
+        ops = [dist.P2POp(dist.irecv, self.buf[r, :tile_count(self.w, self.h, r, self.world)], r) for r in range(1, self.world)]
+        reqs = dist.batch_isend_irecv(ops) if ops else []
         self.buf[0, :mine.shape[0]] = mine
         for q in reqs:
             q.wait()
