@@ -11,14 +11,19 @@ t = rank, rank+N, ... of the same frame, and the tiles are gathered to rank 0
 inside the timed region (strong scaling: the frame is fixed, the work per GPU
 shrinks).  Rank 0 prints ONE JSON line.
 """
-import argparse
-import ctypes as C
-import json
 import os
-import sys
-import time
 
-import numpy as np
+# Frames in flight run on separate HIP streams, which HIP multiplexes onto this many hardware queues (its default
+# is 4, shared with torch's and RCCL's streams).  Must be set before the first HIP call of the process.
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_BENCH_HW_QUEUES", "16")
+
+import argparse  # noqa: E402
+import ctypes as C  # noqa: E402
+import json  # noqa: E402
+import sys  # noqa: E402
+import time  # noqa: E402
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -52,7 +57,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="consecutive frames that may overlap on a GPU (1 = strictly in order; default 2, or 4 with several GPUs, "
+                    help="consecutive frames that may overlap on a GPU (1 = strictly in order; default 4, or 8 with several GPUs, "
                          "where each GPU's share of a frame is too small to fill it)")
     return ap.parse_args()
 
@@ -153,7 +158,7 @@ def main():
     # ---- frame buffers (torch owns the memory; the library gets raw pointers) ----
     # One surface per frame in flight, like a swap chain: frame i renders into surface i % F while
     # frame i-1 is still draining and (with N > 1) being gathered.
-    nf = max(1, min(args.frames_in_flight, 4)) if args.frames_in_flight > 0 else (4 if multi else 2)
+    nf = max(1, min(args.frames_in_flight, 8)) if args.frames_in_flight > 0 else (8 if multi else 4)
     surfaces = [torch.zeros((h, w, 4), dtype=torch.float32, device=dev) for _ in range(nf)]
     surface = surfaces[0]
     pitch = w * 16

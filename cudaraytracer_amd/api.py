@@ -245,7 +245,7 @@ class Context:
         self._check(self.lib.rt_set_tile_order(self.ctx, mode), "rt_set_tile_order")
 
     def set_frames_in_flight(self, frames):
-        """1 = frames run in order on the context's stream; 2..4 = consecutive frames overlap on internal streams."""
+        """1 = frames run in order on the context's stream; 2..8 = consecutive frames overlap on internal streams."""
         self._check(self.lib.rt_set_frames_in_flight(self.ctx, frames), "rt_set_frames_in_flight")
 
     def stream_wait_frame(self, stream_ptr=None, frames_ago=0):

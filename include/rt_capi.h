@@ -334,7 +334,7 @@ int rt_set_tile_order(rt_ctx* ctx, int mode);
  * depend on it. */
 int rt_set_lds_stack(rt_ctx* ctx, int entries);
 
-/* Frames in flight (1..4, default 1).  With 1, rt_render enqueues the frame on the
+/* Frames in flight (1..8, default 1).  With 1, rt_render enqueues the frame on the
  * context's stream, in order, as the reference's cudamain does on the default
  * stream (cudaTracer/Main.cu:92-119).  With more, consecutive rt_render calls run
  * on internal streams and overlap: each frame starts behind everything enqueued
@@ -342,8 +342,12 @@ int rt_set_lds_stack(rt_ctx* ctx, int entries);
  * NOT wait for it.  Frames that overlap must be given different surfaces and aux
  * buffers.  rt_sync waits for all of them; rt_stream_wait_frame orders a stream
  * behind one of them.  Overlap fills the wave slots that the persistent trace
- * kernels leave empty while their last rays finish.  The reference has no
- * counterpart (it synchronises the device after every frame). */
+ * kernels leave empty while their last rays finish.  Each frame in flight runs on
+ * its own HIP stream; HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
+ * (default 4, shared with the caller's streams), so more than two frames only
+ * overlap when the process sets that environment variable higher (e.g. 16) before
+ * its first HIP call.  The reference has no counterpart (it synchronises the device
+ * after every frame). */
 int rt_set_frames_in_flight(rt_ctx* ctx, int frames);
 
 /* Makes `hipStream` (NULL = the context's stream) wait, on the device, for the

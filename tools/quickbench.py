@@ -25,6 +25,7 @@ ap.add_argument("--frames-in-flight", type=int, default=0)
 ap.add_argument("--waves", type=int, default=0)
 ap.add_argument("--tile-order", type=int, default=-1)
 ap.add_argument("--device-bvh", action="store_true")
+ap.add_argument("--stride", type=int, default=1, help="render only tiles 0, stride, 2*stride, ... (one GPU's share of a multi-GPU frame)")
 a = ap.parse_args()
 
 t = time.time()
@@ -67,18 +68,22 @@ with rt.Context(0) as ctx:
     nf = max(a.frames_in_flight, 1)
     surfs = [surf] + [ctx.surface(a.width, a.height)[0] for _ in range(nf - 1)]
     for i in range(2 * nf):
-        ctx.render(ds, scene.opts, scene.camera, surfs[i % nf], pitch)
+        ctx.render(ds, scene.opts, scene.camera, surfs[i % nf], pitch, None, None, 0, a.stride)
     ctx.sync()
     ctx.timing_reset()
     t0 = time.perf_counter()
+    issue = 0.0
     for i in range(a.steps):
-        ctx.render(ds, scene.opts, scene.camera, surfs[i % nf], pitch)
+        ti = time.perf_counter()
+        ctx.render(ds, scene.opts, scene.camera, surfs[i % nf], pitch, None, None, 0, a.stride)
+        issue += time.perf_counter() - ti
+    print(f"host time inside rt_render: {issue/a.steps*1e3:.3f} ms per frame")
     ctx.sync()
     wall = (time.perf_counter() - t0) / a.steps * 1e3
     total, st, n = ctx.timing_read_stages()
     print(f"rays/frame {rays} (primary {c['primary']} shadow {c['shadow']} secondary {c['secondary']}), node/ray {c['node']/rays:.1f} tri/ray {c['tri']/rays:.1f}")
     print(f"frame {total/n:.3f} ms  | primary-trace {st[0]/n:.3f}  shade {st[1]/n:.3f}  shadow-trace {st[2]/n:.3f}  rest {st[3]/n:.3f}  | "
-          f"wall {wall:.3f} ms/frame = {rays/wall/1e3:.1f} Mrays/s", flush=True)
+          f"wall {wall:.3f} ms/frame = {rays/a.stride/wall/1e3:.1f} Mrays/s", flush=True)
     t0 = time.perf_counter()
     for _ in range(5):
         ctx.download_surface(surfs[0], pitch, a.width, a.height)
