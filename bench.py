@@ -45,8 +45,8 @@ def algorithmic_bytes(cnt, pixels):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--scene", default="soup")
     ap.add_argument("--size", type=int, default=1000000, help="triangles (soup / heightfield) or grid side (cubes)")
     ap.add_argument("--width", type=int, default=1920)
