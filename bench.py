@@ -223,6 +223,29 @@ def main():
         elapsed, t_stage = float(t[0].item()), [float(x) for x in t[1:].tolist()]
     frame_ms, closest_ms, shade_ms, shadow_ms, rest_ms = t_stage
 
+    # ---- the kernels on their own (untimed for `value`): with frames in flight a launch shares the GPU with the
+    # neighbouring frames' kernels and its start-to-end time says little about the kernel itself, so the roofline
+    # uses launches that run alone, one frame at a time - the state a rocprofv3 kernel trace of
+    # `bench.py --frames-in-flight 1` records.
+    alone = t_stage
+    if nf > 1:
+        ctx.set_frames_in_flight(1)
+        for _ in range(2):
+            ctx.render(dscene, opts, camera_ref, surfaces[0].data_ptr(), pitch, None, None, rank, world)
+        ctx.sync()
+        ctx.timing_reset()
+        for _ in range(10):
+            ctx.render(dscene, opts, camera_ref, surfaces[0].data_ptr(), pitch, None, None, rank, world)
+        ctx.sync()
+        k_ms, st, n = ctx.timing_read_stages()
+        alone = [k_ms / max(n, 1)] + [x / max(n, 1) for x in st]
+        if multi:
+            t = torch.tensor(alone, dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            alone = [float(x) for x in t.tolist()]
+    in_flight_ms = {"frame": frame_ms, "trace_closest": closest_ms, "shade": shade_ms, "trace_shadow": shadow_ms, "rest": rest_ms}
+    frame_ms, closest_ms, shade_ms, shadow_ms, rest_ms = alone
+
     if rank == 0:
         raw = [int(x) for x in cnt_buf.tolist()]
         sh = dict(zip(("node", "tri", "sphere", "mesh_entry"), raw[9:13]))
@@ -258,7 +281,9 @@ def main():
                        "tile_sharding": f"8x8 tiles, tile t on GPU t % {world}, gathered to GPU0 each frame" if multi else "single GPU",
                        "frames_in_flight": nf,
                        "scene_build_s": round(t_build, 2)},
-            "kernel_ms": {"frame": frame_ms, "trace_closest": closest_ms, "shade": shade_ms, "trace_shadow": shadow_ms, "rest": rest_ms},
+            "kernel_ms": {"frame": frame_ms, "trace_closest": closest_ms, "shade": shade_ms, "trace_shadow": shadow_ms, "rest": rest_ms,
+                          "note": "launches running alone (one frame in flight), measured after the timed region"},
+            "kernel_ms_in_flight": in_flight_ms,
             "roofline": {"bound": "hbm", "kernel": "traceKernel<false,false> (closest hit, primary rays)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic("traceKernel<false, false>", wl_key) if world == 1 else None,
@@ -268,10 +293,12 @@ def main():
                                            "whole frame, by wall clock": {"achieved": gbs(frame_bytes, elapsed / args.steps * 1e3),
                                                                           "algorithmic_bytes": frame_bytes // world}},
                          "note": "algorithmic bytes = 32/box test + 48/triangle test + 20/sphere test + 64/mesh entry + 20/ray hit record, "
-                                 "test counts exact from the counter build of the same kernels; duration from HIP events on the launch stream "
-                                 "(with frames in flight > 1 a launch shares the GPU with the neighbouring frames' kernels, so its duration "
-                                 "is longer than when it runs alone). "
-                                 "The BVH and triangle records (about 100 MB) stay L2 / Infinity-Cache resident, so HBM is the nominal bound only",
+                                 "test counts exact from the counter build of the same kernels; duration = average of 10 launches running "
+                                 "alone (one frame in flight), HIP events on the launch stream; kernel_ms_in_flight holds the start-to-end "
+                                 "times inside the timed, overlapped region. "
+                                 "The BVH and triangle records (about 56 MB) stay L2 / Infinity-Cache resident, so HBM is the nominal bound only: "
+                                 "the figure counts the operands of every test, the caches serve most of them (frac can exceed 1), and "
+                                 "`traffic` is what the memory side really moved per launch (PMC)",
                          "tests_per_ray": {"node": cnt["node"] / rays, "tri": cnt["tri"] / rays,
                                            "closest_node": closest["node"] / max(cnt["primary"] + cnt["secondary"], 1),
                                            "closest_tri": closest["tri"] / max(cnt["primary"] + cnt["secondary"], 1),
