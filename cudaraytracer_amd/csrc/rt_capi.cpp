@@ -84,10 +84,12 @@ struct rt_ctx {
     uint32_t sampleSeed = 1234;
     BuildParams bvhBuild;  // for meshes that arrive without BVH nodes
     int tileOrderMode = RT_TILE_ORDER_CENTER_OUT;
-    std::vector<int32_t> tileOrderHost;
-    void* tileOrderDev = nullptr;
-    size_t tileOrderCap = 0;
-    long long tileOrderKey[6] = {-1, -1, -1, -1, -1, -1};
+    // tile orders already on the device, by (tile grid, shard, frame size); a table is never changed once made
+    struct TileOrder {
+        long long key[6];
+        void* dev;
+    };
+    std::vector<TileOrder> tileOrders;
     int wavesPerCu = 0, wavesForLds = -1;
     // pinned staging for rt_surface_download: two chunks, so that the copy from the device overlaps the copy to the caller
     void* staging[2] = {nullptr, nullptr};
@@ -570,7 +572,8 @@ void rt_destroy(rt_ctx* ctx) {
         if (sl.ready) hipEventDestroy(sl.ready);
         if (sl.done) hipEventDestroy(sl.done);
     }
-    if (ctx->tileOrderDev) hipFree(ctx->tileOrderDev);
+    for (auto& t : ctx->tileOrders)
+        if (t.dev) hipFree(t.dev);
     for (int k = 0; k < 2; ++k) {
         if (ctx->staging[k]) hipHostFree(ctx->staging[k]);
         if (ctx->stagingDone[k]) hipEventDestroy(ctx->stagingDone[k]);
@@ -981,8 +984,15 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     // change, only their order in the queue.
     if (ctx->tileOrderMode == RT_TILE_ORDER_CENTER_OUT) {
         const long long key[6] = {p.tilesX, p.tilesY, tileFirst, tileStride, opts->width, opts->height};
-        if (std::memcmp(key, ctx->tileOrderKey, sizeof key) != 0) {
-            if (int r = syncFrames(ctx)) return r;  // earlier frames may still read the table
+        const void* table = nullptr;
+        for (const auto& t : ctx->tileOrders)
+            if (std::memcmp(key, t.key, sizeof key) == 0) table = t.dev;
+        if (!table) {
+            if (ctx->tileOrders.size() >= 64) {  // a caller cycling through many shardings: start over
+                if (int r = syncFrames(ctx)) return r;
+                for (auto& t : ctx->tileOrders) hipFree(t.dev);
+                ctx->tileOrders.clear();
+            }
             std::vector<std::pair<long long, int32_t>> all((size_t)myTiles);
             const long long cx = opts->width, cy = opts->height;  // twice the image centre
             for (long long k = 0; k < myTiles; ++k) {
@@ -992,19 +1002,22 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
                 all[(size_t)k] = {dx * dx + dy * dy, t};
             }
             std::sort(all.begin(), all.end());
-            ctx->tileOrderHost.resize((size_t)myTiles);
-            for (long long k = 0; k < myTiles; ++k) ctx->tileOrderHost[(size_t)k] = all[(size_t)k].second;
-            if ((size_t)myTiles > ctx->tileOrderCap) {
-                if (ctx->tileOrderDev) hipFree(ctx->tileOrderDev);
-                ctx->tileOrderDev = nullptr;
-                ctx->tileOrderCap = 0;
-                RT_HIP(ctx, hipMalloc(&ctx->tileOrderDev, (size_t)myTiles * sizeof(int32_t)));
-                ctx->tileOrderCap = (size_t)myTiles;
+            std::vector<int32_t> order((size_t)myTiles);
+            for (long long k = 0; k < myTiles; ++k) order[(size_t)k] = all[(size_t)k].second;
+            void* dev = nullptr;
+            RT_HIP(ctx, hipMalloc(&dev, (size_t)myTiles * sizeof(int32_t)));
+            hipError_t ce = hipMemcpy(dev, order.data(), (size_t)myTiles * sizeof(int32_t), hipMemcpyHostToDevice);
+            if (ce != hipSuccess) {
+                hipFree(dev);
+                return fail(ctx, RT_ERR_DEVICE, "tile order upload: %s", hipGetErrorString(ce));
             }
-            RT_HIP(ctx, hipMemcpy(ctx->tileOrderDev, ctx->tileOrderHost.data(), (size_t)myTiles * sizeof(int32_t), hipMemcpyHostToDevice));
-            std::memcpy(ctx->tileOrderKey, key, sizeof key);
+            rt_ctx::TileOrder entry;
+            std::memcpy(entry.key, key, sizeof key);
+            entry.dev = dev;
+            ctx->tileOrders.push_back(entry);
+            table = dev;
         }
-        p.tileOrder = static_cast<const int32_t*>(ctx->tileOrderDev);
+        p.tileOrder = static_cast<const int32_t*>(table);
     }
 
     if (ctx->launchesUsed == ctx->launches.size()) {
