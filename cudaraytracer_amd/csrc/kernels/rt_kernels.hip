@@ -4,10 +4,11 @@
 // node = one invocation of the reference's recursive castRay):
 //
 //   traceKernel<closest>  persistent 64-lane wavefronts; every LANE owns one ray
-//                         and pulls the next one from an atomic work queue as
-//                         soon as its ray ends (wave-level chunks of the queue
-//                         keep neighbouring pixels in one wave); two-level BVH
-//                         walk with the per-lane stack in LDS
+//                         and gets the next one from an atomic work queue after
+//                         its ray ends (wave-level chunks of the queue keep
+//                         neighbouring pixels in one wave); two-level BVH walk,
+//                         box tests per lane, leaf triangles tested by all 64
+//                         lanes together, per-lane stack in an LDS ring
 //   shadeKernel           hit -> surface (st, normal, textures) -> either a
 //                         shading context + shadow work, or child rays
 //                         (ballot-compacted into the next level's queue)
