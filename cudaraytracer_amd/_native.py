@@ -128,6 +128,15 @@ HARNESS = {
     "rth_scene_rotate_lights": (None, [C.c_void_p, C.c_float]),
     "rth_scene_set_camera": (None, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "rth_scene_run_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_char_p, C.c_void_p]),
+    "rth_experiment_open": (C.c_void_p, [C.c_char_p, C.c_char_p]),
+    "rth_experiment_free": (None, [C.c_void_p]),
+    "rth_experiment_name": (C.c_char_p, [C.c_void_p]),
+    "rth_experiment_phase_count": (C.c_int, [C.c_void_p]),
+    "rth_experiment_error_count": (C.c_int, [C.c_void_p]),
+    "rth_experiment_errors": (C.c_char_p, [C.c_void_p]),
+    "rth_experiment_phase": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(RtDeviceOpts), C.POINTER(C.c_int),
+                                       C.POINTER(C.c_float), C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_float)]),
+    "rth_experiment_scene": (C.c_void_p, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
     "rth_write_png": (C.c_int, [C.c_char_p, C.c_void_p, C.c_int, C.c_int]),
     "rth_floats_to_bytes": (None, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "rth_read_png": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -20,8 +20,13 @@ class HostScene:
     reference's FLT_MIN-clamped one (same hits except ties, far fewer tests).
     """
 
-    def __init__(self, name, width, height, size=0, lights=0, max_depth=0, asset_dir=None, tight_bvh=False, device_bvh=False):
+    def __init__(self, name, width, height, size=0, lights=0, max_depth=0, asset_dir=None, tight_bvh=False, device_bvh=False,
+                 _handle=None):
         self.lib = N.load()
+        if _handle is not None:  # a scene some other harness call built (Experiment.scene)
+            self.h = _handle
+            self.name = name
+            return
         self.h = self.lib.rth_scene_create(name.encode(), width, height, size, lights, max_depth,
                                            asset_dir.encode() if asset_dir else None, (1 if tight_bvh else 0) | (2 if device_bvh else 0))
         if not self.h:
@@ -84,6 +89,66 @@ class HostScene:
         p = (C.c_float * 3)(*pos)
         d = (C.c_float * 3)(*direction)
         self.lib.rth_scene_set_camera(self.h, p, d)
+
+
+class Experiment:
+    """An experiment description in the reference's JSON format (csrc/host/ExperimentReader.h,
+    cudaTracer/ExperimentReader.cpp): a name and up to five phases, each a set of option overrides on the defaults.
+
+    Experiment(path) reads a file, Experiment(text=...) a string.  `errors` lists the messages the reader
+    collected (wrong types, missing names, bad JSON); like the reference, reading carries on past them.
+    """
+
+    def __init__(self, path=None, text=None):
+        self.lib = N.load()
+        if (path is None) == (text is None):
+            raise ValueError("Experiment: give a path or a text")
+        self.h = self.lib.rth_experiment_open(str(path).encode() if path is not None else None,
+                                              text.encode() if text is not None else None)
+        if not self.h:
+            raise RtError(self.lib.rth_last_error().decode())
+        self.name = self.lib.rth_experiment_name(self.h).decode()
+        raw = self.lib.rth_experiment_errors(self.h).decode()
+        self.errors = [m for m in raw.split("\n\n") if m]
+        self.phases = [self._phase(i) for i in range(self.lib.rth_experiment_phase_count(self.h))]
+
+    def _phase(self, idx):
+        name, folder, fname = (C.create_string_buffer(512) for _ in range(3))
+        dev = N.RtDeviceOpts()
+        lights, fov = C.c_int(), C.c_float()
+        transform = (C.c_float * 16)()
+        rc = self.lib.rth_experiment_phase(self.h, idx, name, 512, C.byref(dev), C.byref(lights), C.byref(fov), folder, 512, fname, 512,
+                                           transform)
+        if rc != 0:
+            raise RtError(self.lib.rth_last_error().decode())
+        return {
+            "name": name.value.decode(),
+            "device": dev,
+            "lightCnt": lights.value,
+            "fov": fov.value,
+            "model": {"folder": folder.value.decode(), "fname": fname.value.decode(),
+                      "transform": np.array(transform, dtype=np.float32).reshape(4, 4)},
+        }
+
+    def scene(self, idx, asset_dir=None, tight_bvh=False, device_bvh=False, derive_view=False):
+        """The scene of phase idx, assembled like RayTracer::initScene (cudaTracer/RayTracer.cpp:50-78).
+        derive_view: recompute scale / aspect ratio from the phase's fov, width, height (the reference keeps the defaults')."""
+        flags = (1 if tight_bvh else 0) | (2 if device_bvh else 0) | (4 if derive_view else 0)
+        h = self.lib.rth_experiment_scene(self.h, idx, asset_dir.encode() if asset_dir else None, flags)
+        if not h:
+            raise RtError(self.lib.rth_last_error().decode())
+        return HostScene(self.phases[idx]["name"], 0, 0, _handle=h)
+
+    def close(self):
+        if self.h:
+            self.lib.rth_experiment_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def tiles_of_rank(width, height, rank, world, tile=8):

@@ -9,6 +9,7 @@
 #ifndef RT_HOST_RAYTRACER_H
 #define RT_HOST_RAYTRACER_H
 
+#include <cmath>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -50,6 +51,33 @@ class RayTracer {
         return *meshes.back();
     }
     void addLight(const Light& l) { lights.push_back(l); }
+
+    // The ring of options.host.lightCnt lights of RayTracer::addLights (cudaTracer/RayTracer.cpp:80-101): light i
+    // sits at angle i * 2*pi / lightCnt, radius U(10, 50), height U(0, 25), intensity U(0, 0.5) per channel, power
+    // U(0, 25).  The reference draws from the C library's rand(), never seeded, in a Windows build: the generator
+    // here is that runtime's documented LCG (x = x * 214013 + 2531011, output bits 16..30, RAND_MAX 32767) from seed
+    // 1.  The order in which the constructor arguments consume draws is the compiler's choice in the reference
+    // (C++ leaves it unspecified); here it is left to right: power, position x y z, intensity r g b.
+    void addLights(unsigned seed = 1) {
+        unsigned state = seed;
+        auto draw = [&state]() {
+            state = state * 214013u + 2531011u;
+            return (float)((state >> 16) & 0x7fffu) / 32767.0f;
+        };
+        const int cnt = options.host.lightCnt;
+        const float radStep = (2.0f * PI) / cnt;
+        const float intensityFactor = 0.5f, maxDist = 50.0f;
+        for (int i = 0; i < cnt; ++i) {
+            const float power = draw() * 25.0f;
+            const float px = std::sin(i * radStep) * (draw() * (maxDist - 10) + 10);
+            const float py = draw() * 25.0f;
+            const float pz = std::cos(i * radStep) * (draw() * (maxDist - 10) + 10);
+            const float r = draw() * intensityFactor;
+            const float g = draw() * intensityFactor;
+            const float b = draw() * intensityFactor;
+            addLight(Light(Vec3f(px, py, pz), Vec3f(r, g, b), power));
+        }
+    }
 
     // The reference's 10x10 sphere field with a mirror and a glass ball
     // (cudaTracer/RayTracer.cpp:103-132).

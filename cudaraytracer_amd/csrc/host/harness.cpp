@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "CubeModelFactory.h"
+#include "ExperimentReader.h"
 #include "ObjFileReader.h"
 #include "RayTracer.h"
 
@@ -219,38 +220,63 @@ std::unique_ptr<RayTracer> buildHeightfield(int width, int height, int triCnt, i
     return rt;
 }
 
-// cfg "mixed": the reference's default scene shape - sphere field + mirror +
-// glass + textured plane + three mesh instances - with a deterministic light
-// ring.  With an asset directory the plane uses pattern_106 and the meshes are
-// the metal barrel; without one, procedural textures and cubes stand in.
-std::unique_ptr<RayTracer> buildMixed(int width, int height, int lightCnt, int maxDepth, const std::string& assets, BuildOptions bm) {
-    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 90, maxDepth), bm.bounds);
-    rt->addSpheres();
+// The reference's default scene content (cudaTracer/RayTracer.cpp:67-69): sphere field + mirror + glass,
+// textured plane, three mesh instances.  With an asset directory the plane uses pattern_106 and the meshes
+// are the metal barrel (the plastic one ships without its .obj); without one, procedural textures and
+// cubes stand in.
+void addDefaultContent(RayTracer& rt, const std::string& assets, BuildOptions bm) {
+    rt.addSpheres();
     const unsigned char ca[3] = {200, 200, 200}, cb[3] = {70, 70, 90};
     if (!assets.empty()) {
         const std::string t = assets + "/textures/pattern_106/";
-        rt->addPlane(t + "diffus.png", t + "normal.png", t + "specular.png");
+        rt.addPlane(t + "diffus.png", t + "normal.png", t + "specular.png");
     } else {
-        rt->addPlane(checker(64, ca, cb), bumpNormals(64), greyRamp(64));
+        rt.addPlane(checker(64, ca, cb), bumpNormals(64), greyRamp(64));
     }
     Material mtl;
     mtl.materialType = Material::DIFFUSE_AND_GLOSSY;
     const float pos[3][3] = {{0.5f, -3, 9}, {-2, -3, 5}, {-4, -3, 4}};
     if (!assets.empty()) {
-        // cudaTracer/RayTracer.cpp:158-186 with the barrel that ships (the plastic one has no .obj)
+        // cudaTracer/RayTracer.cpp:158-186
         const Mat44f scale = Mat44f::scale(1 / 50.0f, 1 / 50.0f, 1 / 50.0f);
         const std::vector<model::Model> models = ObjFileReader().readFile(assets + "/models/metalBarrel/", "metal_barrel.obj", false);
         if (models.empty()) throw std::runtime_error("metal_barrel.obj: no model read");
         for (int k = 0; k < 3; ++k)
-            rt->addMesh(std::make_unique<DeviceMesh>(models[0], mtl, scale * Mat44f::translate(pos[k][0], pos[k][1], pos[k][2]), bm));
+            rt.addMesh(std::make_unique<DeviceMesh>(models[0], mtl, scale * Mat44f::translate(pos[k][0], pos[k][1], pos[k][2]), bm));
     } else {
         const std::vector<Vertex> verts = CubeModelFactory::createVertices();
         const std::vector<int> inds = CubeModelFactory::createIndicies();
         for (int k = 0; k < 3; ++k)
-            rt->addMesh(std::make_unique<DeviceMesh>(verts, inds, 12, checker(8, ca, cb), bumpNormals(8), greyRamp(8), Texture::CLAMP, mtl,
-                                                     Mat44f::scale(0.6f, 1.0f, 0.6f) * Mat44f::translate(pos[k][0], pos[k][1] + 1.0f, pos[k][2]), bm));
+            rt.addMesh(std::make_unique<DeviceMesh>(verts, inds, 12, checker(8, ca, cb), bumpNormals(8), greyRamp(8), Texture::CLAMP, mtl,
+                                                    Mat44f::scale(0.6f, 1.0f, 0.6f) * Mat44f::translate(pos[k][0], pos[k][1] + 1.0f, pos[k][2]), bm));
     }
+}
+
+// cfg "mixed": the reference's default scene shape with a deterministic light ring.
+std::unique_ptr<RayTracer> buildMixed(int width, int height, int lightCnt, int maxDepth, const std::string& assets, BuildOptions bm) {
+    auto rt = std::make_unique<RayTracer>(baseOptions(width, height, 90, maxDepth), bm.bounds);
+    addDefaultContent(*rt, assets, bm);
     ringLights(*rt, lightCnt < 1 ? 16 : lightCnt, 4242);
+    rt->finalizeScene();
+    return rt;
+}
+
+// One experiment phase: RayTracer::initScene (cudaTracer/RayTracer.cpp:50-78) for the phase's options.  A named
+// model replaces the default content and takes the phase's transform; the lights are the reference's ring.
+std::unique_ptr<RayTracer> buildPhase(const Options& opts, const std::string& assets, BuildOptions bm) {
+    if (opts.device.width < 1 || opts.device.height < 1) throw std::invalid_argument("phase: width and height must be positive");
+    if (opts.host.lightCnt < 0) throw std::invalid_argument("phase: lightCnt must not be negative");
+    auto rt = std::make_unique<RayTracer>(opts, bm.bounds);
+    if (!opts.host.model.fname.empty()) {
+        Material mtl;
+        mtl.materialType = Material::DIFFUSE_AND_GLOSSY;
+        const std::vector<model::Model> models = ObjFileReader().readFile(opts.host.model.folder, opts.host.model.fname, false);
+        if (models.empty()) throw std::runtime_error(opts.host.model.folder + opts.host.model.fname + ": no model read");
+        rt->addMesh(std::make_unique<DeviceMesh>(models[0], mtl, opts.host.model.transform, bm));
+    } else {
+        addDefaultContent(*rt, assets, bm);
+    }
+    rt->addLights();
     rt->finalizeScene();
     return rt;
 }
@@ -362,7 +388,6 @@ void rth_scene_set_camera(rth_scene* h, const float pos[3], const float dir[3]) 
     h->refresh();
 }
 
-// PicDumper: float RGBA -> 8-bit (x256, clamped) -> PNG.
 // The headless frame loop of the reference's RayTracer (cudaTracer/RayTracer.cpp:188-208) on the C++ driver:
 // upload, `frames` times { rotate the lights by dt, set them, render, wait }, then dump the last frame as PNG
 // (PicDumper) and, if `rgba` is given, copy its float pixels out.  The scene's light table keeps the rotation.
@@ -391,6 +416,76 @@ int rth_scene_run_frames(rth_scene* h, int device, int frames, float dt, const c
     return rc;
 }
 
+// ---- experiment files (cudaTracer/ExperimentReader.cpp, cudaTracer/main.cpp:97-135) ----
+struct rth_experiment {
+    std::unique_ptr<ExperimentReader> reader;
+    std::string errors;
+};
+
+// Opens an experiment description: `jsonPath` names a file, or - when it is NULL - `jsonText` holds the JSON.
+// Every phase starts from loadDefaults().  Never NULL for readable arguments: check rth_experiment_errors.
+rth_experiment* rth_experiment_open(const char* jsonPath, const char* jsonText) {
+    if (!jsonPath && !jsonText) {
+        g_error = "rth_experiment_open: neither a path nor a text";
+        return nullptr;
+    }
+    auto* e = new rth_experiment();
+    if (jsonPath)
+        e->reader = std::make_unique<ExperimentReader>(jsonPath, loadDefaults());
+    else
+        e->reader = std::make_unique<ExperimentReader>(ExperimentReader::fromString(jsonText, loadDefaults()));
+    for (const std::string& m : e->reader->errors) e->errors += m + "\n\n";
+    return e;
+}
+void rth_experiment_free(rth_experiment* e) { delete e; }
+const char* rth_experiment_name(rth_experiment* e) { return e->reader->experiment.experimentName.c_str(); }
+int rth_experiment_phase_count(rth_experiment* e) { return e->reader->experiment.phaseCnt; }
+int rth_experiment_error_count(rth_experiment* e) { return (int)e->reader->errors.size(); }
+// The collected messages, each followed by an empty line; "" when the file parsed cleanly.
+const char* rth_experiment_errors(rth_experiment* e) { return e->errors.c_str(); }
+
+// Options of phase `idx`; every output pointer may be NULL.  transform receives the model's 16 floats, row-major.
+int rth_experiment_phase(rth_experiment* e, int idx, char* name, int nameLen, RtDeviceOpts* device, int* lightCnt, float* fov, char* folder,
+                         int folderLen, char* fname, int fnameLen, float* transform) {
+    if (idx < 0 || idx >= e->reader->experiment.phaseCnt) {
+        g_error = "rth_experiment_phase: no such phase";
+        return -1;
+    }
+    const ExperimentPhase& p = e->reader->experiment.phases[idx];
+    if (name) std::snprintf(name, (size_t)nameLen, "%s", p.phaseName.c_str());
+    if (device) {
+        std::memcpy(device, p.opts.device.abi(), sizeof(RtDeviceOpts));
+        device->pad_ = 0;  // the C++ struct's tail padding carries no value
+    }
+    if (lightCnt) *lightCnt = p.opts.host.lightCnt;
+    if (fov) *fov = p.opts.host.fov;
+    if (folder) std::snprintf(folder, (size_t)folderLen, "%s", p.opts.host.model.folder.c_str());
+    if (fname) std::snprintf(fname, (size_t)fnameLen, "%s", p.opts.host.model.fname.c_str());
+    if (transform) std::memcpy(transform, p.opts.host.model.transform.x, 64);
+    return 0;
+}
+
+// The scene of phase `idx`, built as RayTracer::initScene builds it.  flags: bit 0 tight BVH bounds, bit 1 BVHs
+// built on the device, bit 2 re-derive device.scale / imageAspectRatio from the phase's fov, width and height
+// (the reference leaves them at the defaults' values).
+rth_scene* rth_experiment_scene(rth_experiment* e, int idx, const char* assetDir, int flags) {
+    try {
+        if (idx < 0 || idx >= e->reader->experiment.phaseCnt) throw std::invalid_argument("rth_experiment_scene: no such phase");
+        Options opts = e->reader->experiment.phases[idx].opts;
+        if (flags & 4) setView(opts, opts.device.width, opts.device.height, opts.host.fov);
+        const BuildOptions bm((flags & 1) ? BVH::TIGHT_BOUNDS : BVH::REFERENCE_BOUNDS, (flags & 2) != 0);
+        std::unique_ptr<RayTracer> rt = buildPhase(opts, assetDir ? assetDir : "", bm);
+        auto* h = new rth_scene();
+        h->rt = std::move(rt);
+        h->refresh();
+        return h;
+    } catch (const std::exception& ex) {
+        g_error = ex.what();
+        return nullptr;
+    }
+}
+
+// PicDumper: float RGBA -> 8-bit (x256, clamped) -> PNG.
 int rth_write_png(const char* path, const float* rgba, int width, int height) {
     std::vector<float> px(rgba, rgba + (size_t)width * height * 4);
     return PicDumper(width, height).toDisk(px, path) ? 0 : -1;
