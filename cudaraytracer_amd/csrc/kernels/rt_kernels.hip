@@ -117,6 +117,46 @@ __device__ __forceinline__ bool boxSlabs(const float4 n0, const float4 n1, const
     return ok && (tMax > 0);
 }
 
+// The same test on the two boxes of a sibling pair at once (records n0 n1 | n2 n3).  Each plane distance of the
+// first box shares a two-wide operation with the matching one of the second box; every value is formed by the
+// same sequence of roundings as in boxSlabs.
+typedef float F2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void boxPairSlabs(const float4 n0, const float4 n1, const float4 n2, const float4 n3, const V3 o, const V3 inv,
+                                             const bool nx, const bool ny, const bool nz, bool& ok0, bool& ok1, float& tMin0, float& tMin1) {
+    constexpr float kPad = 0x1.000006p+0f;
+    const F2 xn = {nx ? n0.w : n0.x, nx ? n2.w : n2.x}, xf = {nx ? n0.x : n0.w, nx ? n2.x : n2.w};
+    const F2 yn = {ny ? n1.x : n0.y, ny ? n3.x : n2.y}, yf = {ny ? n0.y : n1.x, ny ? n2.y : n3.x};
+    const F2 zn = {nz ? n1.y : n0.z, nz ? n3.y : n2.z}, zf = {nz ? n0.z : n1.y, nz ? n2.z : n3.y};
+    const F2 txMin = (xn - o.x) * inv.x;
+    const F2 txMax = ((xf - o.x) * inv.x) * kPad;
+    const F2 tyMin = (yn - o.y) * inv.y;
+    const F2 tyMax = ((yf - o.y) * inv.y) * kPad;
+    const F2 tzMin = (zn - o.z) * inv.z;
+    const F2 tzMax = (zf - o.z) * inv.z;
+    {
+        float tMin = txMin.x, tMax = txMax.x;
+        bool ok = !(tMin > tyMax.x || tyMin.x > tMax);
+        if (tyMin.x > tMin) tMin = tyMin.x;
+        if (tyMax.x < tMax) tMax = tyMax.x;
+        ok = ok && !(tMin > tzMax.x || tzMin.x > tMax);
+        if (tzMin.x > tMin) tMin = tzMin.x;
+        if (tzMax.x < tMax) tMax = tzMax.x;
+        tMin0 = tMin;
+        ok0 = ok && (tMax > 0);
+    }
+    {
+        float tMin = txMin.y, tMax = txMax.y;
+        bool ok = !(tMin > tyMax.y || tyMin.y > tMax);
+        if (tyMin.y > tMin) tMin = tyMin.y;
+        if (tyMax.y < tMax) tMax = tyMax.y;
+        ok = ok && !(tMin > tzMax.y || tzMin.y > tMax);
+        if (tzMin.y > tMin) tMin = tzMin.y;
+        if (tzMax.y < tMax) tMax = tzMax.y;
+        tMin1 = tMin;
+        ok1 = ok && (tMax > 0);
+    }
+}
+
 // cudaTracer/Sphere.cuh:9-54
 __device__ __forceinline__ bool sphereHit(const DevShape& s, const V3 o, const V3 d, float& tMax) {
     const V3 L = sub(o, mk(s.center));
@@ -370,12 +410,16 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
         ++sp;
     };
     auto pop = [&]() -> uint2 {
+        // the ring slot is read in any case (an LDS read the common path needs anyway); entries older than the
+        // ring come back from global memory
         --sp;
+        uint2 e = stk[(sp & ringMask) * kWave];
+        asm volatile("" : "+v"(e.x), "+v"(e.y));  // keeps this an LDS read of its own instead of one generic-address load
         if (sp < lo) {
             lo = sp;
-            return gstk[(size_t)sp * kWave];
+            e = gstk[(size_t)sp * kWave];
         }
-        return stk[(sp & ringMask) * kWave];
+        return e;
     };
     // enter the node described by reference r (its box test has passed)
     auto enter = [&](unsigned r) {
@@ -539,18 +583,22 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     const float4 L0 = p[0], L1 = p[1], L2 = p[2], L3 = p[3];
                     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
                     float t0, t1;
-                    const bool g0 = boxSlabs(L0, L1, o, inv, nx, ny, nz, t0);
-                    const bool g1 = boxSlabs(L2, L3, o, inv, nx, ny, nz, t1);
+                    bool g0, g1;
+                    boxPairSlabs(L0, L1, L2, L3, o, inv, nx, ny, nz, g0, g1, t0, t1);
                     const unsigned axis = RT_REF_AXIS(cur);
                     const bool single = axis == RT_REF_ROOT_AXIS;  // a root record: there is no sibling
                     // cudaTracer/Mesh.cuh:155-161: with a negative direction along the split axis the
-                    // second child is nearer; the other one waits on the stack
-                    const bool negAxis = !single && (axis == 0 ? nx : (axis == 1 ? ny : nz));
+                    // second child is nearer; the other one waits on the stack.  (Lane predicates are combined
+                    // with and / or rather than selected, which keeps them in scalar mask registers.)
+                    const bool negAxis = (axis == 0 && nx) || (axis == 1 && ny) || (axis == 2 && nz);
                     const unsigned nearRef = __float_as_uint(negAxis ? L3.z : L1.z);
                     const unsigned farRef = __float_as_uint(negAxis ? L1.z : L3.z);
-                    const bool nearGeo = negAxis ? g1 : g0, farGeo = negAxis ? g0 : g1;
-                    const float nearT = negAxis ? t1 : t0, farT = negAxis ? t0 : t1;
-                    const bool farHit = !single && farGeo && farT < tMax;
+                    // near / far outcome = the two boxes' outcomes swapped where negAxis holds: done on the wavefront's
+                    // lane masks (scalar registers), which costs no vector instruction
+                    const unsigned long long mNeg = __ballot(negAxis), mH0 = __ballot(g0 && t0 < tMax), mH1 = __ballot(g1 && t1 < tMax);
+                    const bool nearHit = __builtin_amdgcn_inverse_ballot_w64((mNeg & mH1) | (~mNeg & mH0));
+                    const bool farHit = __builtin_amdgcn_inverse_ballot_w64(((mNeg & mH0) | (~mNeg & mH1)) & ~__ballot(single));
+                    const float farT = negAxis ? t0 : t1;
                     const bool doPush = COUNT ? !single : farHit;
                     // the entry is written in any case (above the top of the stack it is harmless; with a full
                     // ring and nothing to push it goes to the dump slot), which keeps the common path free of branches
@@ -564,7 +612,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     sp += doPush ? 1 : 0;
                     if (COUNT) cNode++;
                     enter(nearRef);
-                    if (!(nearGeo && nearT < tMax)) cur = CUR_POP;
+                    if (!nearHit) cur = CUR_POP;
                 }
             }
             // ================= scene-leaf shapes (per lane) ==================
