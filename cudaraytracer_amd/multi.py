@@ -73,6 +73,12 @@ class TileGather:
         self.full = self.n // world  # tiles every rank has
         self.rem = self.n % world    # ranks below this have one more
         self.mine = tile_ids(width, height, rank, world).to(device)
+        # pixel index (row-major over the surface) of every pixel of this rank's tiles, tile by tile: one gather
+        # brings the tiles out of the surface without re-laying out the whole frame first
+        t = self.mine.view(-1, 1, 1)
+        rows = (t // self.tx) * TILE + torch.arange(TILE, device=device).view(1, TILE, 1)
+        cols = (t % self.tx) * TILE + torch.arange(TILE, device=device).view(1, 1, TILE)
+        self.pixels = (rows * width + cols).reshape(-1)
         if rank == 0:
             per = self.full + (1 if self.rem else 0)
             self.buf = torch.zeros((world, per, TILE, TILE, channels), dtype=dtype, device=device)
@@ -80,8 +86,7 @@ class TileGather:
 
     def tiles(self, surface):
         """[h, w, c] surface -> [tiles, 8, 8, c] of this rank's tiles (a copy)."""
-        t = surface.view(self.ty, TILE, self.tx, TILE, self.c).permute(0, 2, 1, 3, 4).reshape(self.n, TILE, TILE, self.c)
-        return t.index_select(0, self.mine)
+        return surface.view(self.h * self.w, self.c).index_select(0, self.pixels).view(-1, TILE, TILE, self.c)
 
     def gather(self, surface):
         """Every rank passes its own surface (only its tiles are read).  Rank 0 returns the assembled [h, w, c] frame."""
@@ -100,7 +105,7 @@ class TileGather:
             q.wait()
         flat = self.frame.view(self.n, TILE, TILE, self.c)
         # tile k * world + r sits in buf[r, k]
-        flat[: self.full * self.world] = self.buf[:, : self.full].transpose(0, 1).reshape(self.full * self.world, TILE, TILE, self.c)
+        flat[: self.full * self.world].view(self.full, self.world, TILE, TILE, self.c).copy_(self.buf[:, : self.full].transpose(0, 1))
         if self.rem:
             flat[self.full * self.world:] = self.buf[: self.rem, self.full]
         return self.frame.permute(0, 2, 1, 3, 4).reshape(self.h, self.w, self.c)
