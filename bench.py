@@ -57,8 +57,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="consecutive frames that may overlap on a GPU (1 = strictly in order; default 4, or 8 with several GPUs, "
-                         "where each GPU's share of a frame is too small to fill it)")
+                    help="consecutive frames that may overlap on a GPU (1 = strictly in order; default 8, the library's maximum)")
     return ap.parse_args()
 
 
@@ -158,7 +157,7 @@ def main():
     # ---- frame buffers (torch owns the memory; the library gets raw pointers) ----
     # One surface per frame in flight, like a swap chain: frame i renders into surface i % F while
     # frame i-1 is still draining and (with N > 1) being gathered.
-    nf = max(1, min(args.frames_in_flight, 8)) if args.frames_in_flight > 0 else (8 if multi else 4)
+    nf = max(1, min(args.frames_in_flight, 8)) if args.frames_in_flight > 0 else 8
     surfaces = [torch.zeros((h, w, 4), dtype=torch.float32, device=dev) for _ in range(nf)]
     surface = surfaces[0]
     pitch = w * 16
