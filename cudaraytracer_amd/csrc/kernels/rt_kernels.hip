@@ -41,7 +41,7 @@ constexpr unsigned kChunk = RT_CHUNK;  // rays a wavefront takes from the global
 #define RT_REFILL_LANES 24  // a wavefront refills once this many lanes have finished their rays
 #endif
 #ifndef RT_TRI_LANES
-#define RT_TRI_LANES 8  // a triangle phase starts once this many lanes wait in a leaf
+#define RT_TRI_LANES 12  // a triangle phase starts once this many lanes wait in a leaf
 #endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1  // __launch_bounds__ waves per SIMD for the trace kernel

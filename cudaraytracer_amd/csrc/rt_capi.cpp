@@ -68,6 +68,7 @@ struct FrameSlot {
     hipEvent_t done = nullptr;     // recorded behind the frame's last kernel
     hipStream_t lastStream = nullptr;  // stream the slot's latest frame ran on
     bool issued = false;
+    bool mayOverflow = false;  // a frame with reflection / refraction rays ran on this slot since the last rt_sync
 };
 
 struct rt_ctx {
@@ -96,7 +97,10 @@ struct rt_ctx {
     hipEvent_t stagingDone[2] = {nullptr, nullptr};
     hipStream_t copyStream = nullptr;
     std::string error;
-    std::vector<TimedLaunch> launches;  // events of launches since the last reset
+    // Events of the launches since the last rt_timing_reset.  At most kMaxTimedLaunches sets exist; a caller that
+    // never resets keeps rendering, and the timing then covers the latest kMaxTimedLaunches launches.
+    static constexpr size_t kMaxTimedLaunches = 4096;
+    std::vector<TimedLaunch> launches;
     size_t launchesUsed = 0;
 };
 
@@ -597,7 +601,9 @@ int rt_sync(rt_ctx* ctx) {
     if (int r = syncFrames(ctx)) return r;
     uint32_t overflow = 0;
     for (FrameSlot& sl : ctx->slots) {
-        if (!sl.ws.ctl) continue;
+        // only frames that spawn child rays can run out of path nodes
+        if (!sl.ws.ctl || !sl.mayOverflow) continue;
+        sl.mayOverflow = false;
         uint32_t block[CTL_WORDS];
         RT_HIP(ctx, hipMemcpy(block, sl.ws.ctl, sizeof block, hipMemcpyDeviceToHost));
         overflow |= block[CTL_OVERFLOW];
@@ -1020,13 +1026,12 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
         p.tileOrder = static_cast<const int32_t*>(table);
     }
 
-    if (ctx->launchesUsed == ctx->launches.size()) {
-        if (ctx->launches.size() >= 65536) return fail(ctx, RT_ERR_LIMIT, "call rt_timing_reset: too many timed launches");
+    if (ctx->launchesUsed >= ctx->launches.size() && ctx->launches.size() < rt_ctx::kMaxTimedLaunches) {
         TimedLaunch l;
         for (hipEvent_t& e : l.ev) RT_HIP(ctx, hipEventCreate(&e));
         ctx->launches.push_back(l);
     }
-    TimedLaunch& l = ctx->launches[ctx->launchesUsed];
+    TimedLaunch& l = ctx->launches[ctx->launchesUsed % rt_ctx::kMaxTimedLaunches];
     if (forked) {
         RT_HIP(ctx, hipEventRecord(sl.ready, ctx->stream));
         RT_HIP(ctx, hipStreamWaitEvent(exec, sl.ready, 0));
@@ -1035,6 +1040,7 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
     RT_HIP(ctx, hipEventRecord(sl.done, exec));
     sl.issued = true;
+    sl.mayOverflow = sl.mayOverflow || (secondary && opts->maxDepth > 0);
     sl.lastStream = exec;
     ctx->frameCounter++;
     ctx->launchesUsed++;
@@ -1053,7 +1059,8 @@ int rt_timing_read_stages(rt_ctx* ctx, double* totalMs, double* stageMs, int* la
     if (!ctx) return RT_ERR_INVALID;
     if (int r = bind(ctx)) return r;
     double total = 0, stage[4] = {0, 0, 0, 0};
-    for (size_t i = 0; i < ctx->launchesUsed; ++i) {
+    const size_t timed = std::min(ctx->launchesUsed, ctx->launches.size());
+    for (size_t i = 0; i < timed; ++i) {
         TimedLaunch& l = ctx->launches[i];
         RT_HIP(ctx, hipEventSynchronize(l.ev[4]));
         float ms = 0;
@@ -1067,7 +1074,7 @@ int rt_timing_read_stages(rt_ctx* ctx, double* totalMs, double* stageMs, int* la
     if (totalMs) *totalMs = total;
     if (stageMs)
         for (int k = 0; k < 4; ++k) stageMs[k] = stage[k];
-    if (launches) *launches = (int)ctx->launchesUsed;
+    if (launches) *launches = (int)timed;
     return RT_OK;
 }
 

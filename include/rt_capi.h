@@ -292,7 +292,9 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
 /* HIP-event timing of the rt_render calls since the last reset, measured on the
  * stream they ran on.  Call after rt_sync.  totalMs sums the whole per-frame
  * kernel sequence; stageMs[4] (may be NULL) splits it into: closest-hit trace of
- * the primary rays, shading, shadow-ray trace, everything after. */
+ * the primary rays, shading, shadow-ray trace, everything after.  Without a
+ * reset the figures cover the latest 4096 calls; rendering itself never
+ * depends on a reset. */
 int rt_timing_reset(rt_ctx* ctx);
 int rt_timing_read(rt_ctx* ctx, double* totalMs, int* launches);
 int rt_timing_read_stages(rt_ctx* ctx, double* totalMs, double* stageMs, int* launches);

@@ -142,3 +142,29 @@ def test_empty_and_single_tile_shards(gpu_ctx):
     finally:
         gpu_ctx.free(surf)
         gpu_ctx.free_scene(dscene)
+
+
+def test_render_loop_never_runs_out_of_timing_events(gpu_ctx):
+    """A caller that renders frame after frame without ever resetting the timing (the reference's frame loop,
+    RayTracer.cpp:188-208) must keep rendering; the timing then covers the latest 4096 launches."""
+    scene = SphereScene(8, 8, SPHERES, LIGHTS, max_depth=0)
+    dscene = gpu_ctx.upload(C.pointer(scene.desc))
+    surf, pitch = gpu_ctx.surface(8, 8)
+    try:
+        gpu_ctx.timing_reset()
+        for i in range(4300):
+            gpu_ctx.render(dscene, scene.opts, C.pointer(scene.camera), surf, pitch)
+            if i % 512 == 511:
+                gpu_ctx.sync()
+        gpu_ctx.sync()
+        total_ms, launches = gpu_ctx.timing_read()
+        assert launches == 4096 and total_ms > 0
+        first = gpu_ctx.download_surface(surf, pitch, 8, 8)
+        gpu_ctx.timing_reset()
+        gpu_ctx.render(dscene, scene.opts, C.pointer(scene.camera), surf, pitch)
+        gpu_ctx.sync()
+        assert gpu_ctx.timing_read()[1] == 1
+        assert np.array_equal(first, gpu_ctx.download_surface(surf, pitch, 8, 8), equal_nan=True)
+    finally:
+        gpu_ctx.free(surf)
+        gpu_ctx.free_scene(dscene)
