@@ -271,9 +271,6 @@ constexpr unsigned TAG_TRI = 0x80000000u, TAG_SHAPE = 0xC0000000u, IDX_MASK = 0x
 constexpr unsigned STACK_MESH_EXIT = 0xFFFFFFFDu;  // stack marker: the mesh walk is over, restore the world-space ray
 constexpr int HIT_PENDING = -3;                    // hShape while the hit mesh is still being walked
 
-#ifndef RT_WAVE_CHUNKS
-#define RT_WAVE_CHUNKS 4  // chunks of the work queue a wavefront should get at least (0 = every resident wavefront takes part)
-#endif
 #ifndef RT_POP_WHILE
 #define RT_POP_WHILE if  // one pop attempt per iteration of the main loop (`while` = pop until something is entered)
 #endif
@@ -369,10 +366,10 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     const unsigned total = ANY ? P.ctl[CTL_DIFFUSE_CNT] * (unsigned)P.lightCnt : P.ctl[CTL_LEVEL_COUNT + level];
     const unsigned first = ANY ? 0u : P.ctl[CTL_LEVEL_START + level];
     unsigned* const queue = P.ctl + (ANY ? CTL_SHADOW_QUEUE : CTL_TRACE_QUEUE);
-    // With little work, only as many wavefronts take part as get RT_WAVE_CHUNKS chunks each: a wavefront that
-    // refills keeps its lanes busy, one that gets a single chunk only runs it dry, and the slots left free go
-    // to the kernels of other frames in flight.
-    if (RT_WAVE_CHUNKS > 0 && (unsigned long long)blockIdx.x * (kChunk * RT_WAVE_CHUNKS) >= total && blockIdx.x != 0) return;
+    // With little work, only as many wavefronts take part as get P.waveChunks chunks each.  One chunk each spreads
+    // the rays over the most wavefronts (shortest launch when nothing else runs); several make a wavefront refill
+    // its lanes instead of running a single chunk dry, and leave slots free for the kernels of other frames in flight.
+    if ((unsigned long long)blockIdx.x * (kChunk * (unsigned)P.waveChunks) >= total && blockIdx.x != 0) return;
 
     const float4* const blob4 = reinterpret_cast<const float4*>(P.blob);
     const float4* const records = reinterpret_cast<const float4*>(P.blob + P.offRecords);
