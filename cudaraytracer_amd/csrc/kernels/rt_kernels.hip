@@ -90,36 +90,13 @@ __device__ __forceinline__ unsigned laneRank(unsigned long long mask) {
 }
 
 // ---------------------------------------------------------------------------
-// cudaTracer/BoundingBox.cuh:115-139, split in two: everything that does not
-// depend on the ray's current reach (slab overlap and "far plane in front of the
-// origin") is returned as the function value, the entry distance as tMinOut;
-// the node is visited iff  result && tMinOut < ray.tMax  - the reference's final
-// expression.  n0 = {min.x, min.y, min.z, max.x}, n1 = {max.y, max.z, ref, -}.
-// 1 + 2*gamma(3) == 1 + 3*2^-23 in fp32.
-__device__ __forceinline__ bool boxSlabs(const float4 n0, const float4 n1, const V3 o, const V3 inv, const bool nx,
-                                         const bool ny, const bool nz, float& tMinOut) {
-    constexpr float kPad = 0x1.000006p+0f;
-    float tMin = ((nx ? n0.w : n0.x) - o.x) * inv.x;
-    float tMax = ((nx ? n0.x : n0.w) - o.x) * inv.x;
-    const float tyMin = ((ny ? n1.x : n0.y) - o.y) * inv.y;
-    float tyMax = ((ny ? n0.y : n1.x) - o.y) * inv.y;
-    tMax *= kPad;
-    tyMax *= kPad;
-    bool ok = !(tMin > tyMax || tyMin > tMax);
-    if (tyMin > tMin) tMin = tyMin;
-    if (tyMax < tMax) tMax = tyMax;
-    const float tzMin = ((nz ? n1.y : n0.z) - o.z) * inv.z;
-    const float tzMax = ((nz ? n0.z : n1.y) - o.z) * inv.z;
-    ok = ok && !(tMin > tzMax || tzMin > tMax);
-    if (tzMin > tMin) tMin = tzMin;
-    if (tzMax < tMax) tMax = tzMax;
-    tMinOut = tMin;
-    return ok && (tMax > 0);
-}
-
-// The same test on the two boxes of a sibling pair at once (records n0 n1 | n2 n3).  Each plane distance of the
-// first box shares a two-wide operation with the matching one of the second box; every value is formed by the
-// same sequence of roundings as in boxSlabs.
+// cudaTracer/BoundingBox.cuh:115-139 on the two boxes of a sibling pair at once, split in two: everything that
+// does not depend on the ray's current reach (slab overlap and "far plane in front of the origin") comes back
+// as ok0 / ok1, the entry distances as tMin0 / tMin1; a box is visited iff  ok && tMin < ray.tMax  - the
+// reference's final expression.  Records: n0 = {min.x, min.y, min.z, max.x}, n1 = {max.y, max.z, ref, -} for the
+// first box, n2 / n3 likewise for the second.  Each plane distance of the first box shares a two-wide
+// operation with the matching one of the second box; every value is formed by the reference's sequence of
+// roundings.  The far planes of x and y are padded by 1 + 2*gamma(3) == 1 + 3*2^-23 in fp32, z is not.
 typedef float F2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void boxPairSlabs(const float4 n0, const float4 n1, const float4 n2, const float4 n3, const V3 o, const V3 inv,
                                              const bool nx, const bool ny, const bool nz, bool& ok0, bool& ok1, float& tMin0, float& tMin1) {

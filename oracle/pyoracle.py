@@ -10,15 +10,32 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liboracle.so")
-_lib = None
+# the same source at -O3 -march=x86-64-v3 with contraction: NOT the parity reference (its roundings differ), only a
+# faster CPU figure for the bench's baseline
+O3_LIB_PATH = os.path.join(_HERE, "liboracle_o3.so")
+_libs = {}
 
 
-def load():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"{LIB_PATH} missing: run `python -m cudaraytracer_amd.build`")
-        lib = C.CDLL(LIB_PATH)
+def o3_supported():
+    """True if this CPU has what an x86-64-v3 build needs and the -O3 library exists."""
+    if not os.path.exists(O3_LIB_PATH):
+        return False
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = next((line.split(":", 1)[1].split() for line in f if line.startswith("flags")), [])
+    except OSError:
+        return False
+    return {"avx", "avx2", "fma", "bmi1", "bmi2", "f16c", "abm", "movbe"} <= set(flags)
+
+
+def load(o3=False):
+    path = O3_LIB_PATH if o3 else LIB_PATH
+    if path not in _libs:
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `python -m cudaraytracer_amd.build`")
+        if o3 and not o3_supported():
+            raise RuntimeError("this CPU cannot run the x86-64-v3 build of the oracle")
+        lib = C.CDLL(path)
         lib.oracle_render.restype = C.c_int
         lib.oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_int]
@@ -46,8 +63,8 @@ def load():
         lib.oracle_box_pad_factor.restype = C.c_float
         lib.oracle_set_sample_seed.restype = None
         lib.oracle_set_sample_seed.argtypes = [C.c_uint32]
-        _lib = lib
-    return _lib
+        _libs[path] = lib
+    return _libs[path]
 
 
 def _addr(p):
@@ -61,9 +78,10 @@ def _addr(p):
     return C.addressof(p)
 
 
-def render(desc, opts, camera, width, height, rows=None, threads=1, shadow_any_hit=False, want_keys=True, want_counters=True):
+def render(desc, opts, camera, width, height, rows=None, threads=1, shadow_any_hit=False, want_keys=True, want_counters=True,
+           o3=False):
     """Renders rows (start, stop, step) of the frame on the CPU. Returns (rgba, keys, counters)."""
-    lib = load()
+    lib = load(o3)
     rgba = np.zeros((height, width, 4), dtype=np.float32)
     keys = np.full((height, width, 4), -1, dtype=np.int32) if want_keys else None
     cnt = np.zeros(32, dtype=np.uint64) if want_counters else None

@@ -119,3 +119,18 @@ def test_matrix_inverse_host_equals_oracle(rtlib, oracle):
     out = (C.c_float * 16)()
     rtlib.rth_mat_inverse(sing, out)  # singular -> identity (Mat.cuh:193-196)
     assert bytes(out) == bytes(ident)
+
+
+def test_o3_build_of_the_oracle_renders_the_same_scene(oracle):
+    """The -O3 / FMA build that the bench's CPU baseline also times is the same algorithm: its frames agree with the
+    parity build's within the parity tolerance on nearly every pixel (contraction changes roundings, so not on all)."""
+    if not oracle.o3_supported():
+        pytest.skip("CPU without AVX2 / FMA / BMI2")
+    from parity import compare
+
+    scene = rt.HostScene("mixed", 160, 120, 0, 3, 3)
+    a = oracle.render(scene.desc, scene.opts, scene.camera, 160, 120, threads=4)
+    b = oracle.render(scene.desc, scene.opts, scene.camera, 160, 120, threads=4, o3=True)
+    r = compare(b[0], b[1], a[0], a[1])
+    assert r["key_agreement"] >= 0.999 and r["radiance_ok_fraction"] >= 0.999, r
+    assert abs(b[2]["node"] - a[2]["node"]) <= 0.001 * a[2]["node"]
