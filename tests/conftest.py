@@ -34,3 +34,11 @@ def gpu_ctx():
     ctx = rt.Context(0)
     yield ctx
     ctx.close()
+
+
+@pytest.fixture(scope="session")
+def synthetic_assets(tmp_path_factory):
+    """An asset directory shaped like the reference's (OBJ barrel + 1024x1024 PNG maps + plane textures), written once."""
+    import synth_assets
+
+    return synth_assets.write_assets(tmp_path_factory.mktemp("assets"))

@@ -37,6 +37,20 @@ def test_frame_matches_oracle(gpu_ctx, oracle, name, w, h, size, lights, depth, 
     assert np.array_equal(rgba, rgba2, equal_nan=True)
 
 
+# ---- OBJ + PNG assets: reader, decoder, tangents, CLAMP and WRAP texturing of 1024x1024 maps -----------------
+@pytest.mark.parametrize("name,w,h,lights,depth", [("barrel", 200, 150, 4, 2), ("mixed", 160, 120, 10, 3), ("barrel", 97, 61, 1, 0)])
+def test_asset_scenes_match_oracle(gpu_ctx, oracle, synthetic_assets, name, w, h, lights, depth):
+    """The scenes of RayTracer::initScene with file assets (cudaTracer/RayTracer.cpp:134-186): a 488-triangle OBJ barrel
+    with its three maps, instanced with diffuse and mirror materials, on the WRAP-textured plane, with the glass ball."""
+    scene = rt.HostScene(name, w, h, 0, lights, depth, asset_dir=synthetic_assets)
+    assert scene.triangles == 3 * 488 + 2
+    ref_rgba, ref_keys, ref_cnt = oracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=8, shadow_any_hit=True)
+    rgba, keys, cnt = gpu_ctx.render_frame(scene, want_keys=True, want_counters=True)
+    assert_parity(rgba, keys, ref_rgba, ref_keys)
+    assert cnt == ref_cnt, (cnt, ref_cnt)
+    assert cnt["shade_mesh"] > 0.2 * w * h and cnt["tri"] > 0
+
+
 # ---- golden frames (no oracle run involved) -------------------------------------------------
 import os  # noqa: E402
 import sys  # noqa: E402

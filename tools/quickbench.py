@@ -27,11 +27,21 @@ ap.add_argument("--frames-in-flight", type=int, default=0)
 ap.add_argument("--waves", type=int, default=0)
 ap.add_argument("--tile-order", type=int, default=-1)
 ap.add_argument("--device-bvh", action="store_true")
+ap.add_argument("--assets", default=None, help="asset directory for the mixed / barrel scenes; 'synthetic' writes stand-ins to a temp dir")
 ap.add_argument("--stride", type=int, default=1, help="render only tiles 0, stride, 2*stride, ... (one GPU's share of a multi-GPU frame)")
 a = ap.parse_args()
 
+assets = a.assets
+if assets == "synthetic":
+    import tempfile
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    import synth_assets
+
+    assets = synth_assets.write_assets(tempfile.mkdtemp(prefix="rt_assets_"))
 t = time.time()
-scene = rt.HostScene(a.scene, a.width, a.height, a.size, a.lights, a.max_depth, tight_bvh=not a.reference_bvh, device_bvh=a.device_bvh)
+scene = rt.HostScene(a.scene, a.width, a.height, a.size, a.lights, a.max_depth, asset_dir=assets, tight_bvh=not a.reference_bvh,
+                     device_bvh=a.device_bvh)
 print(f"scene {a.scene} size {a.size}: built in {time.time()-t:.2f}s, depth {scene.bvh_depth()}", flush=True)
 with rt.Context(0) as ctx:
     if a.waves:
