@@ -315,24 +315,40 @@ def test_bad_render_arguments(gpu_ctx):
 
 
 # ---- the headline workload at full size ------------------------------------------------------
-def test_full_size_soup_properties(gpu_ctx, oracle):
-    """1080p over the 1M-triangle soup: sampled rows against the oracle, and size-independent properties
-    (determinism, shard composition, ray-count identities)."""
+def test_full_size_soup_frame_and_properties(gpu_ctx, oracle):
+    """The bench workload itself, 1080p over the 1M-triangle soup: the whole frame and its test counts against the
+    oracle, and size-independent properties (determinism, ray-count identities)."""
     w, h = 1920, 1080
     scene = rt.HostScene("soup", w, h, 1000000, 1, 0, tight_bvh=True)
     dscene = gpu_ctx.upload(scene)
     try:
         rgba, keys, cnt = gpu_ctx.render_frame(scene, dscene, want_keys=True, want_counters=True)
-        rows = (3, h, 45)
-        ref_rgba, ref_keys, _ = oracle.render(scene.desc, scene.opts, scene.camera, w, h, rows=rows, threads=16, shadow_any_hit=True)
-        sel = slice(*rows)
-        assert_parity(rgba[sel], keys[sel], ref_rgba[sel], ref_keys[sel])
+        ref_rgba, ref_keys, ref_cnt = oracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=16, shadow_any_hit=True)
+        r = assert_parity(rgba, keys, ref_rgba, ref_keys)
+        assert r["key_mismatches"] == 0 and cnt == ref_cnt, (r, cnt, ref_cnt)
         hit = keys[..., 0] >= 0
         assert cnt["primary"] == w * h
         assert cnt["shade_mesh"] == int(hit.sum()) and cnt["shadow"] == int(hit.sum()) * 1
         assert 0.3 < hit.mean() < 0.9
         again = gpu_ctx.render_frame(scene, dscene, want_keys=True)
         assert np.array_equal(again[1], keys) and np.array_equal(again[0], rgba, equal_nan=True)
+    finally:
+        gpu_ctx.free_scene(dscene)
+
+
+def test_ten_million_triangle_heightfield_at_4k(gpu_ctx, oracle):
+    """The largest configuration: 9 999 392 triangles in one mesh BVH (depth 20, a 2.2 GB scene blob), 3840x2160.
+    Whole frame, hit keys and test counts against the oracle."""
+    w, h = 3840, 2160
+    scene = rt.HostScene("heightfield", w, h, 0, 1, 0, tight_bvh=True)
+    assert scene.triangles == 9999392 and scene.bvh_depth() == (0, 20)
+    dscene = gpu_ctx.upload(scene)
+    try:
+        rgba, keys, cnt = gpu_ctx.render_frame(scene, dscene, want_keys=True, want_counters=True)
+        ref_rgba, ref_keys, ref_cnt = oracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=16, shadow_any_hit=True)
+        r = assert_parity(rgba, keys, ref_rgba, ref_keys)
+        assert r["key_mismatches"] == 0 and cnt == ref_cnt, (r, cnt, ref_cnt)
+        assert cnt["primary"] == w * h and cnt["shadow"] == int((keys[..., 0] >= 0).sum())
     finally:
         gpu_ctx.free_scene(dscene)
 
