@@ -130,7 +130,11 @@ def main():
 
     w, h = args.width, args.height
     ctx = rt.Context(dev_index)
-    stream = torch.cuda.current_stream(dev)
+    # One explicit stream carries everything this process enqueues through torch (copies, RCCL transfers) and is the
+    # library's context stream.  (Torch's default stream is HIP's NULL stream, which the C-ABI reads as "the
+    # context's own stream" and which does not order itself against the library's non-blocking streams.)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
 
     # ---- scene: built on rank 0 by the C++ host API, broadcast as one blob ----
@@ -174,10 +178,12 @@ def main():
     gatherer = mg.TileGather(w, h, rank, world, comm_dev) if multi else None
     issued = [0]
 
+    gathered = [None]  # rank 0: the latest assembled frame
+
     def collect(frames_ago):
         """Orders torch's stream behind the frame issued `frames_ago` calls ago and gathers its tiles to rank 0."""
         ctx.stream_wait_frame(stream.cuda_stream, frames_ago)
-        gatherer.gather(surfaces[(issued[0] - 1 - frames_ago) % nf].to(comm_dev))
+        gathered[0] = gatherer.gather(surfaces[(issued[0] - 1 - frames_ago) % nf].to(comm_dev))
 
     def step():
         ctx.render(dscene, opts, camera_ref, surfaces[issued[0] % nf].data_ptr(), pitch, None, None, rank, world)
@@ -252,6 +258,16 @@ def main():
             t = torch.tensor(alone, dtype=torch.float64, device=comm_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             alone = [float(x) for x in t.tolist()]
+    # ---- the gathered frame against the same frame rendered whole on rank 0 (untimed) ----
+    gather_check = None
+    if multi and rank == 0:
+        whole = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+        ctx.render(dscene, opts, camera_ref, whole.data_ptr(), pitch, None, None, 0, 1)
+        ctx.sync()
+        torch.cuda.synchronize(dev)
+        a, b = gathered[0].to(dev), whole
+        differing = int(((a != b) & ~(torch.isnan(a) & torch.isnan(b))).any(dim=2).sum().item())
+        gather_check = "identical to the frame rendered whole on GPU 0" if differing == 0 else f"{differing} pixels differ from the frame rendered whole on GPU 0"
     in_flight_ms = {"frame": frame_ms, "trace_closest": closest_ms, "shade": shade_ms, "trace_shadow": shadow_ms, "rest": rest_ms}
     frame_ms, closest_ms, shade_ms, shadow_ms, rest_ms = alone
 
@@ -289,6 +305,7 @@ def main():
                        "rays_per_frame": rays, "primary": cnt["primary"], "shadow": cnt["shadow"],
                        "tile_sharding": f"8x8 tiles, tile t on GPU t % {world}, gathered to GPU0 each frame" if multi else "single GPU",
                        "frames_in_flight": nf,
+                       "gathered_frame": gather_check,
                        "scene_build_s": round(t_build, 2)},
             "kernel_ms": {"frame": frame_ms, "trace_closest": closest_ms, "shade": shade_ms, "trace_shadow": shadow_ms, "rest": rest_ms,
                           "note": "launches running alone (one frame in flight), measured after the timed region"},
