@@ -1,4 +1,4 @@
-"""world_size-2 (and 3) runs of the multi-GPU frame logic on the gloo backend:
+"""world_size-2 (and 5) runs of the multi-GPU frame logic on the gloo backend:
 scene sharing, interleaved tile assignment and the gather to rank 0.  The
 per-rank renderer is stood in for by the CPU oracle (each rank traces the frame
 and keeps only its tiles), so the assembled frame must equal a single-process
