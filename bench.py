@@ -111,10 +111,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     import torch
 
-    multi = world > 1
+    # RT_BENCH_FORCE_MULTI=1 (development): take the multi-rank code path with a world of one, e.g. to run its RCCL calls on a one-GPU box
+    multi = world > 1 or os.environ.get("RT_BENCH_FORCE_MULTI") == "1"
     # Rehearsal mode for a box with ONE GPU: every rank uses device 0 and the ranks talk over gloo through host
     # memory.  It exercises this script's multi-rank control flow; its numbers mean nothing.
-    rehearsal = multi and os.environ.get("RT_BENCH_REHEARSAL") == "1"
+    rehearsal = world > 1 and os.environ.get("RT_BENCH_REHEARSAL") == "1"
     dev_index = 0 if rehearsal else local_rank
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
