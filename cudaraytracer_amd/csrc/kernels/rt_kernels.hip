@@ -497,50 +497,74 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                 if (part) {
                     rayBuf[2 * rank] = make_float4(o.x, o.y, o.z, __uint_as_float(next));
                     rayBuf[2 * rank + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(end));
+                    if (ANY) tBuf[rank] = tMax;  // a shadow ray's reach never shrinks: the testing lanes can apply it themselves
                 }
                 __syncthreads();
                 const int rounds = (nPart + 7) >> 3;
-                for (int r = 0; r < rounds; ++r) {
+                // ANY: lanes whose triangle the ray accepts, per round (bit = lane: 8 bits per participating ray)
+                unsigned long long accepted[kTriPart / 8] = {};
+#pragma unroll
+                for (int r = 0; r < kTriPart / 8; ++r) {
+                    if (r >= rounds) break;
                     const int rr = r * 8 + (lane >> 3);
                     const unsigned k = (unsigned)lane & 7u;
                     const float4 A = rayBuf[2 * rr], B = rayBuf[2 * rr + 1];
                     const unsigned idx = __float_as_uint(A.w) + k;
                     float t = -1.0f, u = 0.0f, v = 0.0f;
+                    bool solved = false;
                     if (rr < nPart && idx < __float_as_uint(B.w)) {
                         const float4* rec = records + 3 * (size_t)idx;
                         const float4 r0 = rec[0], r1 = rec[1];
                         const float e2z = reinterpret_cast<const float*>(rec + 2)[0];
                         float tt, uu, vv;
                         if (triangleSolve(r0, r1, e2z, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), tt, uu, vv)) {
+                            solved = true;
                             t = tt;
                             u = uu;
                             v = vv;
                         }
                     }
-                    // a rejected or absent triangle is stored as t = -1, which the owner's "t < 0" test discards
-                    tBuf[rr * 8 + k] = t;
-                    uvBuf[rr * 8 + k] = make_float2(u, v);
+                    if (ANY) {
+                        // cudaTracer/Mesh.cuh:205-208 against the reach the ray came with
+                        const float reach = tBuf[rr < nPart ? rr : 0];
+                        accepted[r] = __ballot(solved && !(t < 0.0f) && !(reach < t));
+                    } else {
+                        // a rejected or absent triangle is stored as t = -1, which the owner's "t < 0" test discards
+                        tBuf[rr * 8 + k] = t;
+                        uvBuf[rr * 8 + k] = make_float2(u, v);
+                    }
                 }
-                __syncthreads();
+                if (!ANY) __syncthreads();
                 if (part) {
-                    // cudaTracer/Mesh.cuh:141-146 + 205-208: leaf triangles in order; a hit needs t >= 0 and t <= reach,
-                    // so a later hit at equal t replaces an earlier one
-                    const float4 ta = reinterpret_cast<const float4*>(tBuf)[2 * rank], tb = reinterpret_cast<const float4*>(tBuf)[2 * rank + 1];
-                    const float ts[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
                     int win = -1;
+                    if (ANY) {
+                        // the first accepted triangle of the leaf ends the walk (later ones cannot change the answer)
+                        unsigned long long m = accepted[0];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const bool acc = !(ts[k] < 0.0f) && !(tMax < ts[k]) && !(ANY && win >= 0);
-                        tMax = acc ? ts[k] : tMax;
-                        win = acc ? k : win;
+                        for (int r = 1; r < kTriPart / 8; ++r) m = (rank >> 3) == (unsigned)r ? accepted[r] : m;
+                        const unsigned bits = (unsigned)(m >> ((rank & 7u) * 8u)) & 0xffu;
+                        win = bits ? __ffs((int)bits) - 1 : -1;
+                    } else {
+                        // cudaTracer/Mesh.cuh:141-146 + 205-208: leaf triangles in order; a hit needs t >= 0 and t <= reach,
+                        // so a later hit at equal t replaces an earlier one
+                        const float4 ta = reinterpret_cast<const float4*>(tBuf)[2 * rank], tb = reinterpret_cast<const float4*>(tBuf)[2 * rank + 1];
+                        const float ts[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const bool acc = !(ts[k] < 0.0f) && !(tMax < ts[k]);
+                            tMax = acc ? ts[k] : tMax;
+                            win = acc ? k : win;
+                        }
                     }
                     const unsigned left = end - next;
                     if (COUNT) cTri += (ANY && win >= 0) ? (unsigned)win + 1u : (left < 8u ? left : 8u);
                     if (win >= 0) {
-                        const float2 uv = uvBuf[rank * 8 + win];
-                        hu = uv.x;
-                        hv = uv.y;
-                        hTri = (int)(next + (unsigned)win);
+                        if (!ANY) {
+                            const float2 uv = uvBuf[rank * 8 + win];
+                            hu = uv.x;
+                            hv = uv.y;
+                            hTri = (int)(next + (unsigned)win);
+                        }
                         hShape = HIT_PENDING;
                     }
                     const unsigned nn = next + 8u;
