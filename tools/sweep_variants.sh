@@ -1,5 +1,6 @@
-for v in "" t6 t12 t16 t16p32 t12p24 r16 r32; do
-  if [ -n "$v" ]; then export RT_LIB=$PWD/variants/librt_$v.so; else unset RT_LIB; fi
+# usage: tools/sweep_variants.sh name...   ("base" = the default build); prints bench and in-order timings per variant
+for v in "$@"; do
+  if [ "$v" != "base" ]; then export RT_LIB=$PWD/variants/librt_$v.so; else unset RT_LIB; fi
   timeout -k 10 100 python -u tools/quickbench.py --steps 20 > gpurun_out/sw_q_$v.log 2>&1 || exit 1
   timeout -k 10 100 python -u bench.py --no-cpu --steps 60 > gpurun_out/sw_b_$v.log 2>&1 || exit 1
   q=$(grep "^frame" gpurun_out/sw_q_$v.log | cut -c1-110)
