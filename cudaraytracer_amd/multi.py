@@ -88,8 +88,9 @@ class TileGather:
         """[h, w, c] surface -> [tiles, 8, 8, c] of this rank's tiles (a copy)."""
         return surface.view(self.h * self.w, self.c).index_select(0, self.pixels).view(-1, TILE, TILE, self.c)
 
-    def gather(self, surface):
-        """Every rank passes its own surface (only its tiles are read).  Rank 0 returns the assembled [h, w, c] frame."""
+    def gather(self, surface, assemble=True):
+        """Every rank passes its own surface (only its tiles are read).  Rank 0 returns the assembled [h, w, c] frame,
+        or, with assemble=False, leaves it in tile order for a later assembled() call (one pass over the frame less)."""
         mine = self.tiles(surface)
         # Both sides use the batched point-to-point call: on RCCL it puts rank 0's N-1 receives into ONE group, so
         # they run concurrently over the peers' separate xGMI links, and it keeps sender and receiver on the same
@@ -108,4 +109,8 @@ class TileGather:
         flat[: self.full * self.world].view(self.full, self.world, TILE, TILE, self.c).copy_(self.buf[:, : self.full].transpose(0, 1))
         if self.rem:
             flat[self.full * self.world:] = self.buf[: self.rem, self.full]
+        return self.assembled() if assemble else None
+
+    def assembled(self):
+        """Rank 0: the latest gathered frame as [h, w, c] (a copy)."""
         return self.frame.permute(0, 2, 1, 3, 4).reshape(self.h, self.w, self.c)
