@@ -90,9 +90,22 @@ def build_oracle(force=False):
     return ORACLE_LIB
 
 
+EXAMPLE_SRC = os.path.join(ROOT, "examples", "headless_tracer.cpp")
+EXAMPLE_BIN = os.path.join(ROOT, "examples", "headless_tracer")
+
+
+def build_example(force=False):
+    """The standalone C++ driver: host classes + C-ABI, linked against the library."""
+    if force or _newer(EXAMPLE_BIN, [EXAMPLE_SRC, LIB] + [f for f in _sources() if f.endswith(".h")]):
+        _run([HIPCC, "-x", "c++", *HOST_FLAGS, EXAMPLE_SRC, "-L" + PKG, "-lrt_gfx950", "-lz", "-Wl,-rpath,$ORIGIN/../cudaraytracer_amd",
+              "-o", EXAMPLE_BIN])
+    return EXAMPLE_BIN
+
+
 def build_all(force=False):
     build_library(force)
     build_oracle(force)
+    build_example(force)
 
 
 if __name__ == "__main__":

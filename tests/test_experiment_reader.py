@@ -279,3 +279,28 @@ def test_cli_reports_reader_errors_and_missing_phases(tmp_path, capsys):
     ok.write_text('{"name": "o", "phases": [{"name": "p", "options": {}}]}')
     assert cli.main([str(ok), "3", "--out", ""]) == 1          # no such phase: refused before anything touches a GPU
     assert "phase 3 does not exist" in capsys.readouterr().err
+
+
+# ---- the standalone C++ driver (examples/headless_tracer.cpp) ------------------------------------------------------
+
+def test_cpp_driver_reads_the_experiment_and_fails_loudly_without_a_gpu(tmp_path):
+    """Everything up to rt_create runs on the host: arguments, the reader, the scene.  Without a GPU the program says so
+    and exits with status 1 (there is no CPU rendering path)."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "headless_tracer")
+    if not os.path.exists(exe):
+        pytest.skip("examples/headless_tracer not built")
+    doc = tmp_path / "exp.json"
+    doc.write_text(json.dumps({"name": "cli", "phases": [{"name": "small", "options": {"width": 64, "height": 48, "lightCnt": 2, "fov": 70}}]}))
+    r = subprocess.run([exe, str(doc), "4"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 1 and "phase 4 does not exist" in r.stderr
+    assert "exp name: cli" in r.stdout and "phase name: small" in r.stdout and "'fov' must be of type float!" in r.stderr
+    r = subprocess.run([exe, "a", "1", "extra"], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 2 and "usage" in r.stderr
+    import torch
+
+    if not torch.cuda.is_available():
+        r = subprocess.run([exe, str(doc), "0", "--out", str(tmp_path / "f.png")], capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 1 and "rt_create" in r.stderr and not (tmp_path / "f.png").exists()
