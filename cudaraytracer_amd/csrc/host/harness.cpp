@@ -39,6 +39,20 @@ struct Pcg32 {
     }
     float uniform() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }  // [0, 1)
     float uniform(float lo, float hi) { return lo + (hi - lo) * uniform(); }
+    // three draws, x first: written out because the order in which a constructor's arguments are evaluated is
+    // the compiler's choice, and the scenes must not depend on it
+    Vec3f uniform3(float lo, float hi) {
+        const float x = uniform(lo, hi);
+        const float y = uniform(lo, hi);
+        const float z = uniform(lo, hi);
+        return Vec3f(x, y, z);
+    }
+    Vec3f uniform3(float xlo, float xhi, float ylo, float yhi, float zlo, float zhi) {
+        const float x = uniform(xlo, xhi);
+        const float y = uniform(ylo, yhi);
+        const float z = uniform(zlo, zhi);
+        return Vec3f(x, y, z);
+    }
 };
 
 TextureSource checker(unsigned n, const unsigned char a[3], const unsigned char b[3]) {
@@ -87,9 +101,11 @@ void ringLights(RayTracer& rt, int count, uint64_t seed) {
     const float radStep = (2.0f * PI) / count;
     for (int i = 0; i < count; ++i) {
         const float power = rng.uniform(0, 25.0f);
-        const Vec3f position(std::sin(i * radStep) * rng.uniform(10, 50), rng.uniform(0, 25.0f),
-                             std::cos(i * radStep) * rng.uniform(10, 50));
-        const Vec3f intensity(rng.uniform(0, 0.5f), rng.uniform(0, 0.5f), rng.uniform(0, 0.5f));
+        const float radiusX = rng.uniform(10, 50);
+        const float height = rng.uniform(0, 25.0f);
+        const float radiusZ = rng.uniform(10, 50);
+        const Vec3f position(std::sin(i * radStep) * radiusX, height, std::cos(i * radStep) * radiusZ);
+        const Vec3f intensity = rng.uniform3(0, 0.5f);
         rt.addLight(Light(position, intensity, power));
     }
 }
@@ -141,9 +157,9 @@ std::unique_ptr<RayTracer> buildSoup(int width, int height, int triCnt, int ligh
     verts.reserve((size_t)triCnt * 3);
     inds.reserve((size_t)triCnt * 3);
     for (int t = 0; t < triCnt; ++t) {
-        const Vec3f c(rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(-50, 50));
-        const Vec3f e1(rng.uniform(-0.75f, 0.75f), rng.uniform(-0.75f, 0.75f), rng.uniform(-0.75f, 0.75f));
-        const Vec3f e2(rng.uniform(-0.75f, 0.75f), rng.uniform(-0.75f, 0.75f), rng.uniform(-0.75f, 0.75f));
+        const Vec3f c = rng.uniform3(-50, 50);
+        const Vec3f e1 = rng.uniform3(-0.75f, 0.75f);
+        const Vec3f e2 = rng.uniform3(-0.75f, 0.75f);
         const Vec3f n = e1.cross(e2).normalized();
         verts.push_back(Vertex(c, n, Vec2f(0.0f, 0.0f)));
         verts.push_back(Vertex(c + e1, n, Vec2f(1.0f, 0.0f)));
@@ -161,9 +177,12 @@ std::unique_ptr<RayTracer> buildSoup(int width, int height, int triCnt, int ligh
         rt->addLight(Light(Vec3f(0, 200, -120), Vec3f(0.5f, 0.5f, 0.5f), 25));
     } else {
         Pcg32 lr(77);
-        for (int i = 0; i < lightCnt; ++i)
-            rt->addLight(Light(Vec3f(lr.uniform(-150, 150), lr.uniform(100, 250), lr.uniform(-200, -80)),
-                               Vec3f(lr.uniform(0.1f, 0.5f), lr.uniform(0.1f, 0.5f), lr.uniform(0.1f, 0.5f)), lr.uniform(10, 40)));
+        for (int i = 0; i < lightCnt; ++i) {
+            const Vec3f position = lr.uniform3(-150, 150, 100, 250, -200, -80);
+            const Vec3f intensity = lr.uniform3(0.1f, 0.5f);
+            const float power = lr.uniform(10, 40);
+            rt->addLight(Light(position, intensity, power));
+        }
     }
     rt->finalizeScene();
     return rt;
@@ -213,9 +232,12 @@ std::unique_ptr<RayTracer> buildHeightfield(int width, int height, int triCnt, i
     if (lightCnt < 1) lightCnt = 1;
     rt->addLight(Light(Vec3f(30, 120, 60), Vec3f(0.5f, 0.5f, 0.45f), 120));
     Pcg32 lr(78);
-    for (int i = 1; i < lightCnt; ++i)
-        rt->addLight(Light(Vec3f(lr.uniform(-90, 90), lr.uniform(60, 140), lr.uniform(10, 190)),
-                           Vec3f(lr.uniform(0.1f, 0.4f), lr.uniform(0.1f, 0.4f), lr.uniform(0.1f, 0.4f)), lr.uniform(40, 120)));
+    for (int i = 1; i < lightCnt; ++i) {
+        const Vec3f position = lr.uniform3(-90, 90, 60, 140, 10, 190);
+        const Vec3f intensity = lr.uniform3(0.1f, 0.4f);
+        const float power = lr.uniform(40, 120);
+        rt->addLight(Light(position, intensity, power));
+    }
     rt->finalizeScene();
     return rt;
 }
