@@ -209,6 +209,12 @@ def main():
 
     ctx.sync()
     ctx.set_frames_in_flight(nf)
+    # set-up, not warm-up: one frame per slot, so that every frame in flight has its stream and workspace (a few ms of
+    # allocations each) before anything is timed, whatever --warmup says
+    for _ in range(nf):
+        step()
+    drain()
+    ctx.sync()
     for _ in range(args.warmup):
         step()
     drain()
