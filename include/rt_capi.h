@@ -284,8 +284,9 @@ void rt_device_free(rt_ctx* ctx, void* devPtr);
  * kernel runs persistent 64-lane wavefronts over 8x8-pixel tiles.  The call
  * enqueues on the context's stream and returns; rt_sync waits.  `aux` may be
  * NULL.  Parity with the reference is defined for samples == 1 (its jitter
- * RNG, cudaTracer/Main.cu:108-110, is not reproducible); samples > 1 is
- * rejected. */
+ * RNG, cudaTracer/Main.cu:108-110, is not reproducible); samples 2..RT_MAX_SAMPLES
+ * jitter every sample by rt_sample_jitter and average them as
+ * cudaTracer/Main.cu:66-82 does. */
 int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCamera* cam,
               void* devSurface, size_t pitch, int blockDim, const RtFrameAux* aux);
 
@@ -361,7 +362,8 @@ int rt_stream_wait_frame(rt_ctx* ctx, void* hipStream, int framesAgo);
 int rt_set_trace_waves(rt_ctx* ctx, int wavesPerCu);
 
 /* cu_initCurand / cu_cleanCurand (cudaTracer/Main.cu:113-150) have no
- * counterpart: samples == 1 draws no random numbers. */
+ * counterpart: the jitter is a hash of (seed, pixel, sample, axis) and keeps
+ * no state. */
 
 #ifdef __cplusplus
 }
