@@ -57,3 +57,56 @@ def test_command_line_runs_one_phase(tmp_path, capsys):
     assert (record["width"], record["height"], record["triangles"], record["lights"], record["rounds"]) == (96, 80, 2, 2, 1)
     assert record["run_s"] > 0 and "exp name: gpu run" in captured.err
     assert Image.open(out).size == (96, 80)
+
+
+GRID_MTL = "newmtl mat\nKd 1 1 1\nmap_Kd d.png\nmap_bump n.png\nmap_Ks s.png\n"
+
+
+def write_grid_model(folder):
+    """Two 8x8-quad grids with vertices on integer coordinates, facing a camera at the origin that looks along +z: box
+    planes and triangle edges pass exactly through the camera axis (x = 0, y = 0)."""
+    lines = ["mtllib grid.mtl"]
+    for z in (5.0, 7.0):
+        for y in range(-4, 5):
+            for x in range(-4, 5):
+                lines.append(f"v {x} {y} {z}")
+    for y in range(9):
+        for x in range(9):
+            lines.append(f"vt {x / 8} {y / 8}")
+    lines += ["vn 0 0 -1", "usemtl mat"]
+    for layer in range(2):
+        base = layer * 81
+        for y in range(8):
+            for x in range(8):
+                a, b, c, d = (base + y * 9 + x + 1, base + y * 9 + x + 2, base + (y + 1) * 9 + x + 2, base + (y + 1) * 9 + x + 1)
+                ta, tb, tc, td = y * 9 + x + 1, y * 9 + x + 2, (y + 1) * 9 + x + 2, (y + 1) * 9 + x + 1
+                if (x + y + layer) % 3 == 0:
+                    continue  # holes, so that rays also reach the second layer
+                # counter-clockwise seen from the camera side (-z): the front face
+                lines.append(f"f {a}/{ta}/1 {d}/{td}/1 {c}/{tc}/1 {b}/{tb}/1")
+    (folder / "grid.obj").write_text("\n".join(lines) + "\n")
+    (folder / "grid.mtl").write_text(GRID_MTL)
+    Image.new("RGBA", (4, 4), (180, 120, 60, 255)).save(folder / "d.png")
+    Image.new("RGBA", (1, 1), (128, 128, 255, 255)).save(folder / "n.png")
+    Image.new("RGBA", (1, 1), (200, 200, 200, 255)).save(folder / "s.png")
+
+
+@pytest.mark.parametrize("w,h", [(33, 33), (5, 5), (1, 1), (7, 3), (64, 48)])
+@pytest.mark.parametrize("tight", [False, True])
+def test_rays_along_box_planes_and_triangle_edges(gpu_ctx, oracle, tmp_path, w, h, tight):
+    """Odd frame sizes put a primary ray exactly on the camera axis: direction (0, 0, 1), so two reciprocals are
+    infinite, and with box planes at x = 0 and y = 0 the slab test forms 0 * inf = NaN (BoundingBox.cuh:115-139);
+    the ray also runs along shared triangle edges, where u or v is exactly 0 (Mesh.cuh:190-203).  Hit keys, radiance
+    and the test counts must equal the oracle's, with the reference's box bounds and with tight ones."""
+    write_grid_model(tmp_path)
+    exp = rt.Experiment(text=json.dumps({"name": "axes", "phases": [{"name": "grid", "options": {
+        "model": {"folder": str(tmp_path) + "/", "fname": "grid.obj"}, "lightCnt": 2, "width": w, "height": h, "fov": 90.0,
+        "maxDepth": 0}}]}))
+    assert exp.errors == []
+    scene = exp.scene(0, derive_view=True, tight_bvh=tight)
+    ref_rgba, ref_keys, ref_cnt = oracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=4, shadow_any_hit=True)
+    rgba, keys, cnt = gpu_ctx.render_frame(scene, want_keys=True, want_counters=True)
+    r = assert_parity(rgba, keys, ref_rgba, ref_keys)
+    assert r["key_mismatches"] == 0 and cnt == ref_cnt, (r, cnt, ref_cnt)
+    if w >= 33:
+        assert (ref_keys[..., 0] >= 0).mean() > 0.3 and ref_cnt["tri"] > 0
