@@ -168,3 +168,18 @@ def test_render_loop_never_runs_out_of_timing_events(gpu_ctx):
     finally:
         gpu_ctx.free(surf)
         gpu_ctx.free_scene(dscene)
+
+
+def test_total_internal_reflection_inside_a_glass_sphere(gpu_ctx, oracle):
+    """The camera sits inside a glass ball.  Beyond the critical angle `refract` returns the zero vector
+    (tracer.cu:110-114), the zero-direction ray is traced all the same (tracer.cu:125-128), and Sphere::intersect answers
+    it with t = -0/0 = NaN (Sphere.cuh:9-54): those pixels are NaN in the reference.  They are reproduced, not hidden."""
+    inside_glass = [([0.0, 0.0, 1.5], 2.0, 1, 1.5), ([0.0, 0.0, 6.0], 1.5, 0, 1.3), ([2.5, 0.5, 5.0], 1.0, 2, 64.0), ([0.0, -101.0, 6.0], 100.0, 0, 1.3)]
+    gpu_ctx.set_path_budget(16)
+    try:
+        for depth in (2, 3):
+            rgba, keys, cnt = render_both(gpu_ctx, oracle, SphereScene(96, 64, inside_glass, LIGHTS, max_depth=depth))
+            nan_pixels = int(np.isnan(rgba).any(-1).sum())
+            assert nan_pixels > 1000 and nan_pixels < 96 * 64   # render_both has checked that they are the oracle's
+    finally:
+        gpu_ctx.set_path_budget(3)
