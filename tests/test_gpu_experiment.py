@@ -110,3 +110,36 @@ def test_rays_along_box_planes_and_triangle_edges(gpu_ctx, oracle, tmp_path, w, 
     assert r["key_mismatches"] == 0 and cnt == ref_cnt, (r, cnt, ref_cnt)
     if w >= 33:
         assert (ref_keys[..., 0] >= 0).mean() > 0.3 and ref_cnt["tri"] > 0
+
+
+def test_texture_coordinates_outside_the_unit_square(gpu_ctx, oracle, tmp_path):
+    """A model whose UVs run from -2 to 3 over a 5x3 texture of distinct texels (CLAMP addressing, CudaMesh.h:85-104):
+    bilinear taps left of texel 0 and right of the last one, the fp64 weight path (Texture.cuh:33-69), normal-map and
+    specular taps included."""
+    write_grid_model(tmp_path)
+    text = (tmp_path / "grid.obj").read_text().splitlines()
+    out = []
+    for line in text:
+        if line.startswith("vt "):
+            _, u, v = line.split()
+            out.append(f"vt {float(u) * 5 - 2:.6f} {float(v) * 5 - 2:.6f}")
+        else:
+            out.append(line)
+    (tmp_path / "grid.obj").write_text("\n".join(out) + "\n")
+    rng = np.random.default_rng(5)
+    for name in ("d.png", "n.png", "s.png"):
+        px = rng.integers(0, 256, size=(3, 5, 4), dtype=np.uint8)
+        px[..., 3] = 255
+        if name == "n.png":
+            px[..., 2] = 255   # normals that still point out of the surface
+        Image.fromarray(px, "RGBA").save(tmp_path / name)
+    exp = rt.Experiment(text=json.dumps({"name": "uv", "phases": [{"name": "grid", "options": {
+        "model": {"folder": str(tmp_path) + "/", "fname": "grid.obj"}, "lightCnt": 3, "width": 120, "height": 90, "fov": 90.0,
+        "maxDepth": 0}}]}))
+    scene = exp.scene(0, derive_view=True, tight_bvh=True)
+    ref_rgba, ref_keys, ref_cnt = oracle.render(scene.desc, scene.opts, scene.camera, 120, 90, threads=4, shadow_any_hit=True)
+    rgba, keys, cnt = gpu_ctx.render_frame(scene, want_keys=True, want_counters=True)
+    r = assert_parity(rgba, keys, ref_rgba, ref_keys)
+    assert r["key_mismatches"] == 0 and cnt == ref_cnt and r["max_rel"] < 1e-5, r
+    hit = ref_keys[..., 0] >= 0
+    assert hit.mean() > 0.3 and len(np.unique(to_8bit(ref_rgba)[hit][:, :3], axis=0)) > 50   # the texture shows
