@@ -97,7 +97,7 @@ def test_gamma_and_background_options(gpu_ctx, oracle):
 
 
 # ---- several samples per pixel ----------------------------------------------------------------
-@pytest.mark.parametrize("name,samples,depth,w,h", [("mixed", 4, 3, 96, 64), ("soup", 3, 0, 101, 50), ("cubes", 16, 2, 64, 48)])
+@pytest.mark.parametrize("name,samples,depth,w,h", [("mixed", 4, 3, 96, 64), ("soup", 3, 0, 101, 50), ("cubes", 16, 2, 64, 48), ("mixed", 64, 1, 33, 17)])
 def test_multi_sample_frames(gpu_ctx, oracle, name, samples, depth, w, h):
     """samples > 1: the jitter is rt_sample_jitter on both sides (the reference's curand draw is not reproducible), the
     samples are summed in order and divided as in Main.cu:66-82; the hit key is sample 0's."""
