@@ -90,15 +90,30 @@ def cpu_baseline(scene, args):
                       f"; rows interleaved over {threads} threads, any-hit shadow rays, same BVH as the GPU run; value = the faster build"}
 
 
-def pmc_traffic(kernel, workload_key):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/traffic.json), or None."""
+def pmc_table(workload_key):
+    """Per-kernel figures of the committed PMC passes for this workload (profiles/traffic.json), or {}."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        table = json.load(open(path))
+        return json.load(open(path)).get(workload_key, {})
     except (OSError, ValueError):
-        return None
-    entry = table.get(workload_key, {}).get(kernel)
+        return {}
+
+
+def pmc_traffic(kernel, workload_key):
+    """HBM bytes per launch of `kernel` from the committed PMC passes, or None."""
+    entry = pmc_table(workload_key).get(kernel)
     return None if entry is None else entry.get("hbm_bytes_per_launch")
+
+
+def pmc_valu_issue_fraction(workload_key, ms_per_step, cu_count=256, clock_hz=2.4e9):
+    """Share of the SIMDs' issue cycles that the frame's vector instructions take: every launch of a frame (SQ_INSTS_VALU
+    of the committed PMC pass, 4 cycles per wavefront-wide instruction) over 4 SIMDs x CUs x clock x frame time."""
+    table = pmc_table(workload_key)
+    frame_kernels = ["traceKernel<false, false>", "traceKernel<true, false>", "shadeKernel<false>", "accumKernel", "finalizeKernel"]
+    insts = [table.get(k, {}).get("valu_insts_per_launch") for k in frame_kernels]
+    if any(v is None for v in insts[:2]) or ms_per_step <= 0:
+        return None
+    return 4.0 * sum(v for v in insts if v) / (4 * cu_count * clock_hz * ms_per_step * 1e-3)
 
 
 def main():
@@ -341,7 +356,13 @@ def main():
             # test, 31 per mesh entry, over the frame's wall-clock time; peak = CUs x 128 lanes x 2 (FMA) x clock
             "valu": {"achieved": (24 * cnt["node"] + 60 * cnt["tri"] + 30 * cnt["sphere"] + 31 * cnt["mesh_entry"]) / world /
                                  (elapsed / args.steps) / 1e12,
-                     "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s"},
+                     "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     # measured counterpart: SIMD issue cycles taken by the frame's vector instructions (PMC pass of the same
+                     # workload) over the cycles available in this run's frame time; None without that pass or with N > 1
+                     "issue_fraction": pmc_valu_issue_fraction(wl_key, elapsed / args.steps * 1e3) if world == 1 else None,
+                     "note": "achieved = algorithmic flops of the tests (no selects, compares, address or stack work; no FMA "
+                             "contraction, so half the peak is out of reach by construction); issue_fraction says how busy the "
+                             "vector units really are"},
         }
         if not args.no_cpu and args.cpu_seconds > 0 and not multi:
             out["cpu_baseline"] = cpu_baseline(scene, args)

@@ -24,5 +24,6 @@ pass tcp TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_su
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
+pass ta TA_TA_BUSY_sum TA_BUSY_avr TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum
 python3 profiles/summarize_pmc.py "$OUT" > "$OUT/summary.txt" 2>&1; tail -60 "$OUT/summary.txt"
 echo done

@@ -3,8 +3,8 @@
 
   summarize_pmc.py <dir> [--traffic-json profiles/traffic.json --workload KEY]
 
-With --traffic-json the HBM bytes per launch of every kernel that has FETCH_SIZE and
-WRITE_SIZE samples are merged into that file:
+With --traffic-json the HBM bytes per launch (and the vector instructions per launch, SQ_INSTS_VALU) of every kernel
+that has FETCH_SIZE and WRITE_SIZE samples are merged into that file:
   hbm = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024
 (both counters are in KB; on gfx950 FETCH_SIZE tallies 128-byte fabric reads at 64 bytes, so it is
 doubled; for this kernel's divergent 64-byte line reads the factor is uncalibrated, which makes the
@@ -52,6 +52,8 @@ for k, d in sorted(agg.items()):
         fetch = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]) * 1024
         write = sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"]) * 1024
         traffic[k] = {"fetch_size_bytes_raw": fetch, "write_size_bytes": write, "hbm_bytes_per_launch": 2 * fetch + write}
+        if "SQ_INSTS_VALU" in d:  # wavefront-wide vector instructions per launch (4 SIMD cycles each)
+            traffic[k]["valu_insts_per_launch"] = sum(d["SQ_INSTS_VALU"]) / len(d["SQ_INSTS_VALU"])
         print(f"   => HBM bytes per launch: 2 x {fetch/1e6:.1f} MB + {write/1e6:.1f} MB = {(2*fetch+write)/1e6:.1f} MB")
 if args.traffic_json and traffic:
     table = {}
