@@ -196,7 +196,7 @@ def main():
 
     def collect(frames_ago):
         """Orders torch's stream behind the frame issued `frames_ago` calls ago and gathers its tiles to rank 0
-        (where the frame then sits in tile order: 8x8-pixel blocks, row-major over the tile grid)."""
+        (where the frame then sits as 8x8-pixel tiles, rank by rank; TileGather.assembled() lays it out as rows)."""
         ctx.stream_wait_frame(stream.cuda_stream, frames_ago)
         gatherer.gather(surfaces[(issued[0] - 1 - frames_ago) % nf].to(comm_dev), assemble=False)
 

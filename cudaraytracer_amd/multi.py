@@ -90,8 +90,13 @@ class TileGather:
 
     def gather(self, surface, assemble=True):
         """Every rank passes its own surface (only its tiles are read).  Rank 0 returns the assembled [h, w, c] frame,
-        or, with assemble=False, leaves it in tile order for a later assembled() call (one pass over the frame less)."""
-        mine = self.tiles(surface)
+        or, with assemble=False, leaves the tiles as they arrived (rank by rank) for a later assembled() call."""
+        if self.rank == 0:
+            # rank 0's own tiles go straight into their place in the receive buffer
+            own = self.buf[0, : self.pixels.numel() // (TILE * TILE)].view(-1, self.c)
+            torch.index_select(surface.view(self.h * self.w, self.c), 0, self.pixels, out=own)
+        else:
+            mine = self.tiles(surface)
         # Both sides use the batched point-to-point call: on RCCL it puts rank 0's N-1 receives into ONE group, so
         # they run concurrently over the peers' separate xGMI links, and it keeps sender and receiver on the same
         # communicator.
@@ -101,16 +106,15 @@ class TileGather:
             return None
         ops = [dist.P2POp(dist.irecv, self.buf[r, :tile_count(self.w, self.h, r, self.world)], r) for r in range(1, self.world)]
         reqs = dist.batch_isend_irecv(ops) if ops else []
-        self.buf[0, :mine.shape[0]] = mine
         for q in reqs:
             q.wait()
-        flat = self.frame.view(self.n, TILE, TILE, self.c)
-        # tile k * world + r sits in buf[r, k]
-        flat[: self.full * self.world].view(self.full, self.world, TILE, TILE, self.c).copy_(self.buf[:, : self.full].transpose(0, 1))
-        if self.rem:
-            flat[self.full * self.world:] = self.buf[: self.rem, self.full]
         return self.assembled() if assemble else None
 
     def assembled(self):
-        """Rank 0: the latest gathered frame as [h, w, c] (a copy)."""
+        """Rank 0: the latest gathered frame as [h, w, c] (a copy).  The gather leaves the tiles rank by rank
+        (tile k * world + r sits in buf[r, k]); here they are interleaved into tile order and laid out as rows."""
+        flat = self.frame.view(self.n, TILE, TILE, self.c)
+        flat[: self.full * self.world].view(self.full, self.world, TILE, TILE, self.c).copy_(self.buf[:, : self.full].transpose(0, 1))
+        if self.rem:
+            flat[self.full * self.world:] = self.buf[: self.rem, self.full]
         return self.frame.permute(0, 2, 1, 3, 4).reshape(self.h, self.w, self.c)
