@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     // With little work, only as many wavefronts take part as get P.waveChunks chunks each.  One chunk each spreads
     // the rays over the most wavefronts (shortest launch when nothing else runs); several make a wavefront refill
     // its lanes instead of running a single chunk dry, and leave slots free for the kernels of other frames in flight.
-    const unsigned waveChunks = (unsigned)P.waveChunks + (total >= 6000u * kChunk ? 2u : 0u);
+    const unsigned waveChunks = (unsigned)(total >= 6000u * kChunk ? P.waveChunksLarge : P.waveChunks);
     if ((unsigned long long)blockIdx.x * (kChunk * waveChunks) >= total && blockIdx.x != 0) return;
 
     const float4* const blob4 = reinterpret_cast<const float4*>(P.blob);

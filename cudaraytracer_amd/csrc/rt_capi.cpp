@@ -948,8 +948,9 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     p.traceWaves = (ctx->maxWavesPerCu > 0 ? std::min(ctx->wavesPerCu, ctx->maxWavesPerCu) : ctx->wavesPerCu) * ctx->cuCount;
 
     // measured on whole frames, on small reflection levels and on one GPU's share of a multi-GPU frame: 2 and 8 are slower;
-    // launches with more than 6000 chunks (a half or a quarter of a 1080p frame) do 2-5 % better with 6, which the kernel picks itself
+    // launches with more than 6000 chunks (a half or a quarter of a 1080p frame) do 2-5 % better with 6 when frames overlap
     p.waveChunks = 4;
+    p.waveChunksLarge = ctx->framesInFlight > 1 ? 6 : 4;  // alone on the machine, a launch is shortest with the most wavefronts
     p.tileFirst = tileFirst;
     p.tileStride = tileStride;
     p.tileCnt = (int)myTiles;

@@ -177,6 +177,7 @@ struct FrameParams {
     uint64_t offRecords;
     int32_t traceWaves;                      // wavefronts of the persistent trace kernels
     int32_t waveChunks;                      // 64-ray chunks a wavefront should get at least before another one joins in
+    int32_t waveChunksLarge;                 // the same for launches of 6000 chunks and more
     // workspace (device pointers)
     uint32_t* ctl;          // CTL_WORDS
     float4* hit;            // [nodeCap] {t, u, v, shape slot as int bits (-1 miss, -2 outside the frame)}
