@@ -15,7 +15,7 @@ import os
 
 # Frames in flight run on separate HIP streams, which HIP multiplexes onto this many hardware queues (its default
 # is 4, shared with torch's and RCCL's streams).  Must be set before the first HIP call of the process.
-os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_BENCH_HW_QUEUES", "16")
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_BENCH_HW_QUEUES", "32")
 
 import argparse  # noqa: E402
 import ctypes as C  # noqa: E402
@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="consecutive frames that may overlap on a GPU (1 = strictly in order; default 8, the library's maximum)")
+                    help="consecutive frames that may overlap on a GPU (1 = strictly in order, at most 16; default 12)")
     return ap.parse_args()
 
 
@@ -187,7 +187,7 @@ def main():
     # ---- frame buffers (torch owns the memory; the library gets raw pointers) ----
     # One surface per frame in flight, like a swap chain: frame i renders into surface i % F while
     # frame i-1 is still draining and (with N > 1) being gathered.
-    nf = max(1, min(args.frames_in_flight, 8)) if args.frames_in_flight > 0 else 8
+    nf = max(1, min(args.frames_in_flight, 16)) if args.frames_in_flight > 0 else 12
     surfaces = [torch.zeros((h, w, 4), dtype=torch.float32, device=dev) for _ in range(nf)]
     surface = surfaces[0]
     pitch = w * 16

@@ -193,7 +193,7 @@ struct FrameParams {
     uint2* stackSpill;      // [traceWaves * (stackEntries + RT_MESH_ENTRY_SLOTS) * 64] older stack entries + parked world-space rays
 };
 
-#define RT_MAX_FRAMES_IN_FLIGHT 8
+#define RT_MAX_FRAMES_IN_FLIGHT 16
 
 // Enqueues all kernels of one frame on `stream` (no host synchronisation).
 // `stageEvents`: optional hipEvent_t[5] recorded at frame start, after the level-0 closest-hit

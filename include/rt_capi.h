@@ -337,7 +337,7 @@ int rt_set_tile_order(rt_ctx* ctx, int mode);
  * depend on it. */
 int rt_set_lds_stack(rt_ctx* ctx, int entries);
 
-/* Frames in flight (1..8, default 1).  With 1, rt_render enqueues the frame on the
+/* Frames in flight (1..16, default 1).  With 1, rt_render enqueues the frame on the
  * context's stream, in order, as the reference's cudamain does on the default
  * stream (cudaTracer/Main.cu:92-119).  With more, consecutive rt_render calls run
  * on internal streams and overlap: each frame starts behind everything enqueued
@@ -348,7 +348,8 @@ int rt_set_lds_stack(rt_ctx* ctx, int entries);
  * kernels leave empty while their last rays finish.  Each frame in flight runs on
  * its own HIP stream; HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
  * (default 4, shared with the caller's streams), so more than two frames only
- * overlap when the process sets that environment variable higher (e.g. 16) before
+ * overlap when the process sets that environment variable higher (at least the
+ * number of frames in flight plus the caller's own streams, e.g. 32) before
  * its first HIP call.  The reference has no counterpart (it synchronises the device
  * after every frame). */
 int rt_set_frames_in_flight(rt_ctx* ctx, int frames);

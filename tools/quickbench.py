@@ -8,7 +8,7 @@ import os
 import sys
 import time
 
-os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_BENCH_HW_QUEUES", "16")  # frames in flight need more hardware queues than the 4 a box exports
+os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("RT_BENCH_HW_QUEUES", "32")  # frames in flight need more hardware queues than the 4 a box exports
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import cudaraytracer_amd as rt  # noqa: E402
