@@ -140,6 +140,14 @@ int bind(rt_ctx* ctx) {
 
 size_t alignUp(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
+// Fills fresh device memory and returns only when the fill has finished.  (A plain hipMemset runs on the NULL stream,
+// which is not ordered against the non-blocking streams the frames run on and need not have finished when it
+// returns: a late fill would wipe what a frame has written meanwhile.)
+hipError_t fillNow(void* dev, int value, size_t bytes, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(dev, value, bytes, stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(stream);
+}
+
 // Levels below the root of a flattened tree; also validates child / primitive ranges.
 int treeDepth(const RtLinearNode* nodes, int nodeCnt, int primCnt, int* maxLeafPrims, std::string* err) {
     struct Item {
@@ -496,7 +504,7 @@ int ensureWorkspace(rt_ctx* ctx, Workspace& w, hipStream_t stream, int nodeCap, 
     }
     const size_t n = (size_t)nc;
     RT_HIP(ctx, hipMalloc(&w.ctl, CTL_WORDS * sizeof(uint32_t)));
-    RT_HIP(ctx, hipMemset(w.ctl, 0, CTL_WORDS * sizeof(uint32_t)));
+    RT_HIP(ctx, fillNow(w.ctl, 0, CTL_WORDS * sizeof(uint32_t), stream));
     RT_HIP(ctx, hipMalloc(&w.hit, n * 16));
     RT_HIP(ctx, hipMalloc(&w.hitTri, n * 4));
     RT_HIP(ctx, hipMalloc(&w.color, n * 16));
@@ -811,7 +819,7 @@ int rt_surface_create(rt_ctx* ctx, int width, int height, void** devSurface, siz
     const size_t p = alignUp((size_t)width * 16, 256);
     void* d = nullptr;
     RT_HIP(ctx, hipMalloc(&d, p * height));
-    RT_HIP(ctx, hipMemset(d, 0x01, p * height));  // the reference fills new surfaces with 0x01 bytes
+    RT_HIP(ctx, fillNow(d, 0x01, p * height, ctx->stream));  // the reference fills new surfaces with 0x01 bytes
     *devSurface = d;
     *pitch = p;
     return RT_OK;
@@ -863,7 +871,7 @@ int rt_device_alloc(rt_ctx* ctx, size_t bytes, void** devPtr) {
     if (int r = bind(ctx)) return r;
     void* d = nullptr;
     RT_HIP(ctx, hipMalloc(&d, bytes));
-    RT_HIP(ctx, hipMemset(d, 0, bytes));
+    RT_HIP(ctx, fillNow(d, 0, bytes, ctx->stream));
     *devPtr = d;
     return RT_OK;
 }

@@ -208,23 +208,27 @@ def test_tile_shards_compose_the_frame(gpu_ctx, world):
         gpu_ctx.free_scene(dscene)
 
 
-def test_frames_in_flight_overlap_without_mixing(gpu_ctx):
-    """Three frames in flight, six frames of two different scenes into six surfaces: each equals its in-order render."""
+@pytest.mark.parametrize("in_flight,frames", [(3, 6), (16, 40)])
+def test_frames_in_flight_overlap_without_mixing(gpu_ctx, in_flight, frames):
+    """Several frames in flight, frames of two different scenes into their own surfaces (twice round the slots and
+    more): each equals its in-order render."""
     w, h = 160, 96
     scenes = [rt.HostScene("mixed", w, h, 0, 3, 3), rt.HostScene("soup", w, h, 30000, 2, 0, tight_bvh=True)]
     dscenes = [gpu_ctx.upload(s) for s in scenes]
     expect = [gpu_ctx.render_frame(s, d, want_keys=True) for s, d in zip(scenes, dscenes)]
-    surfs = [gpu_ctx.surface(w, h) for _ in range(6)]
-    keys = [gpu_ctx.alloc(w * h * 16) for _ in range(6)]
-    gpu_ctx.set_frames_in_flight(3)
+    surfs = [gpu_ctx.surface(w, h) for _ in range(frames)]
+    keys = [gpu_ctx.alloc(w * h * 16) for _ in range(frames)]
+    with pytest.raises(rt.RtError):
+        gpu_ctx.set_frames_in_flight(17)
+    gpu_ctx.set_frames_in_flight(in_flight)
     try:
-        for i in range(6):
+        for i in range(frames):
             gpu_ctx.render(dscenes[i % 2], scenes[i % 2].opts, scenes[i % 2].camera, surfs[i][0], surfs[i][1], keys[i])
         # a stream can be ordered behind one frame without a host wait
         gpu_ctx.stream_wait_frame(None, 0)
         gpu_ctx.stream_wait_frame(None, 2)
         gpu_ctx.sync()
-        for i in range(6):
+        for i in range(frames):
             rgba = gpu_ctx.download_surface(surfs[i][0], surfs[i][1], w, h)
             k = gpu_ctx.download(keys[i], (h, w, 4), np.int32)
             assert np.array_equal(k, expect[i % 2][1]), i
