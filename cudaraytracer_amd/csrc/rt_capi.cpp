@@ -143,6 +143,13 @@ size_t alignUp(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 // Fills fresh device memory and returns only when the fill has finished.  (A plain hipMemset runs on the NULL stream,
 // which is not ordered against the non-blocking streams the frames run on and need not have finished when it
 // returns: a late fill would wipe what a frame has written meanwhile.)
+// Host-to-device copy that has reached the device when it returns (a blocking hipMemcpy from pageable memory is
+// allowed to return once the data is staged; the frames' non-blocking streams would not wait for the rest).
+hipError_t uploadNow(void* dev, const void* host, size_t bytes, hipStream_t stream) {
+    hipError_t e = hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(stream);
+}
+
 hipError_t fillNow(void* dev, int value, size_t bytes, hipStream_t stream) {
     hipError_t e = hipMemsetAsync(dev, value, bytes, stream);
     return e != hipSuccess ? e : hipStreamSynchronize(stream);
@@ -710,7 +717,7 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
     if (bind(ctx)) return nullptr;
     unsigned char* dev = nullptr;
     hipError_t e = hipMalloc((void**)&dev, host.size());
-    if (e == hipSuccess) e = hipMemcpy(dev, host.data(), host.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = uploadNow(dev, host.data(), host.size(), ctx->stream);
     if (e != hipSuccess) {
         fail(ctx, RT_ERR_DEVICE, "scene upload (%zu bytes): %s", host.size(), hipGetErrorString(e));
         if (dev) hipFree(dev);
@@ -721,7 +728,7 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
         const RtMesh& m = desc->meshes[b.mesh];
         int32_t* devTris = nullptr;
         e = hipMalloc((void**)&devTris, (size_t)m.triangleCnt * sizeof(RtTriangle));
-        if (e == hipSuccess) e = hipMemcpy(devTris, m.triangles, (size_t)m.triangleCnt * sizeof(RtTriangle), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = uploadNow(devTris, m.triangles, (size_t)m.triangleCnt * sizeof(RtTriangle), ctx->stream);
         int degenerate = 0;
         if (e == hipSuccess) {
             b.job.nodes = b.table.data();
@@ -798,7 +805,7 @@ int rt_scene_set_lights(rt_scene* scene, const RtLight* lights, int lightCnt) {
     if (int r = bind(ctx)) return r;
     // frames already issued (on the context's stream or on the in-flight slots) keep the lights they were issued with
     if (int r = syncFrames(ctx)) return r;
-    RT_HIP(ctx, hipMemcpy(scene->blob + scene->header.offLights, lights, (size_t)lightCnt * sizeof(RtLight), hipMemcpyHostToDevice));
+    RT_HIP(ctx, uploadNow(scene->blob + scene->header.offLights, lights, (size_t)lightCnt * sizeof(RtLight), ctx->stream));
     return RT_OK;
 }
 
@@ -1024,7 +1031,7 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
             for (long long k = 0; k < myTiles; ++k) order[(size_t)k] = all[(size_t)k].second;
             void* dev = nullptr;
             RT_HIP(ctx, hipMalloc(&dev, (size_t)myTiles * sizeof(int32_t)));
-            hipError_t ce = hipMemcpy(dev, order.data(), (size_t)myTiles * sizeof(int32_t), hipMemcpyHostToDevice);
+            hipError_t ce = uploadNow(dev, order.data(), (size_t)myTiles * sizeof(int32_t), ctx->stream);
             if (ce != hipSuccess) {
                 hipFree(dev);
                 return fail(ctx, RT_ERR_DEVICE, "tile order upload: %s", hipGetErrorString(ce));
