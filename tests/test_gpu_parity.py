@@ -357,6 +357,22 @@ def test_ten_million_triangle_heightfield_at_4k(gpu_ctx, oracle):
         gpu_ctx.free_scene(dscene)
 
 
+@pytest.mark.parametrize("name,size,lights,depth", [("soup", 50000, 2, 0), ("mixed", 0, 2, 2)])
+def test_8k_frame(gpu_ctx, oracle, name, size, lights, depth):
+    """7680x4320: 33 M pixels, with the mixed scene up to 100 M path nodes - index arithmetic at its largest.  Rows
+    sampled across the frame against the oracle, ray-count identities over the whole frame."""
+    w, h = 7680, 4320
+    scene = rt.HostScene(name, w, h, size, lights, depth, tight_bvh=True)
+    rgba, keys, cnt = gpu_ctx.render_frame(scene, want_keys=True, want_counters=True)
+    rows = (7, h, 431)
+    ref_rgba, ref_keys, _ = oracle.render(scene.desc, scene.opts, scene.camera, w, h, rows=rows, threads=16, shadow_any_hit=True)
+    sel = slice(*rows)
+    r = assert_parity(rgba[sel], keys[sel], ref_rgba[sel], ref_keys[sel])
+    assert r["key_mismatches"] == 0
+    assert cnt["primary"] == w * h and cnt["shade_mesh"] + cnt["shade_sphere"] >= int((keys[..., 0] >= 0).sum())
+    assert np.all(rgba[..., 3] == 1.0)
+
+
 def test_cpp_driver_frame_loop_and_png_dump(oracle, tmp_path):
     """RayTracer.h (the C++ mirror of cudaTracer/RayTracer.cpp) drives three frames with moving lights through the
     C-ABI and dumps the last one; the oracle renders the same final state."""
