@@ -1,7 +1,8 @@
-"""ctypes binding of librt_gfx950.so: the C-ABI (include/rt_capi.h) and the
-host-API harness entry points (csrc/host/harness.cpp).
+"""ctypes binding of librt_gfx950.so, the C-ABI (include/rt_capi.h), and of
+librt_host.so, the C++ host classes behind flat entry points
+(csrc/host/harness.cpp).
 
-The library is never built or substituted here: if it is missing, loading
+The libraries are never built or substituted here: if one is missing, loading
 fails with an error that names the build command.
 """
 import ctypes as C
@@ -10,6 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # RT_LIB (development only) selects another build of the same library, e.g. a tuning variant
 LIB_PATH = os.environ.get("RT_LIB") or os.path.join(_HERE, "librt_gfx950.so")
+HOST_LIB_PATH = os.path.join(_HERE, "librt_host.so")
 
 RT_COUNTER_NAMES = ["primary", "shadow", "secondary", "node", "tri", "sphere", "mesh_entry", "shade_mesh", "shade_sphere"]
 RT_COUNTER_CNT = 32
@@ -114,6 +116,8 @@ C_ABI = {
     "rt_set_tile_order": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_sample_seed": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rt_set_device_bvh": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "rt_set_workspace_guards": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rt_check_workspace_guards": (C.c_int, [C.c_void_p]),
 }
 
 HARNESS = {
@@ -151,20 +155,33 @@ HARNESS = {
 _lib = None
 
 
+class _Libraries:
+    """Both libraries behind one namespace: rt_* come from the C-ABI library, rth_* from the host library."""
+
+    def __init__(self, capi, host):
+        self.capi = capi
+        self.host = host
+
+    def __getattr__(self, name):
+        return getattr(self.host if name.startswith("rth_") else self.capi, name)
+
+
 def load():
-    """Loads librt_gfx950.so (once) and types every entry point."""
+    """Loads librt_gfx950.so and librt_host.so (once) and types every entry point."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -m cudaraytracer_amd.build` "
-            "(hipcc --offload-arch=gfx950). There is no fallback path.")
-    lib = C.CDLL(LIB_PATH)
-    for table in (C_ABI, HARNESS):
+    for path in (LIB_PATH, HOST_LIB_PATH):
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: build it with `python -m cudaraytracer_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    capi = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)  # the host library's rt_* references resolve to this very build
+    host = C.CDLL(HOST_LIB_PATH)
+    for lib, table in ((capi, C_ABI), (host, HARNESS)):
         for name, (res, args) in table.items():
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = _Libraries(capi, host)
+    return _lib

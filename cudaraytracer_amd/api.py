@@ -274,6 +274,12 @@ class Context:
     def sync(self):
         self._check(self.lib.rt_sync(self.ctx), "rt_sync")
 
+    def set_workspace_guards(self, nbytes):
+        self._check(self.lib.rt_set_workspace_guards(self.ctx, nbytes), "rt_set_workspace_guards")
+
+    def check_workspace_guards(self):
+        self._check(self.lib.rt_check_workspace_guards(self.ctx), "rt_check_workspace_guards")
+
     def set_stream(self, stream_ptr):
         self._check(self.lib.rt_set_stream(self.ctx, stream_ptr), "rt_set_stream")
 

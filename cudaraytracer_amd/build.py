@@ -1,6 +1,8 @@
 """Builds the native pieces in-tree.
 
-  cudaraytracer_amd/librt_gfx950.so  HIP kernels (gfx950) + C-ABI + C++ host API
+  cudaraytracer_amd/librt_gfx950.so  HIP kernels (gfx950) + C-ABI: exports include/rt_capi.h and nothing else
+  cudaraytracer_amd/librt_host.so    C++ host API (csrc/host) behind flat rth_* entry points: scene generators,
+                                     experiment reader, OBJ / PNG readers, self-test; calls the C-ABI library
   oracle/liboracle.so                CPU restatement used by the tests only
 
 Both are plain compiler invocations (hipcc cross-compiles without a GPU).
@@ -13,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "cudaraytracer_amd")
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "librt_gfx950.so")
+HOST_LIB = os.path.join(PKG, "librt_host.so")
 ORACLE_SRC = os.path.join(ROOT, "oracle", "oracle.cpp")
 ORACLE_LIB = os.path.join(ROOT, "oracle", "liboracle.so")
 ORACLE_O3_LIB = os.path.join(ROOT, "oracle", "liboracle_o3.so")
@@ -71,11 +74,20 @@ def build_library(force=False, extra_device_flags=(), out=None, tag=""):
     bvh_force, force = force, (force and not tag)
     compile_one(os.path.join(CSRC, "kernels", "rt_bvh_build.hip"), os.path.join(bvh_obj_dir, "rt_bvh_build.o"), [HIPCC, *DEVICE_FLAGS])
     force = bvh_force
-    for rel in ("rt_capi.cpp", os.path.join("host", "harness.cpp"), os.path.join("host", "host_selftest.cpp")):
-        compile_one(os.path.join(CSRC, rel), os.path.join(objdir, os.path.basename(rel).replace(".cpp", ".o")),
-                    [HIPCC, "-x", "c++", *HOST_FLAGS, "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"])
-    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, "-lz"])
+    host_cmd = [HIPCC, "-x", "c++", *HOST_FLAGS, "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
+    compile_one(os.path.join(CSRC, "rt_capi.cpp"), os.path.join(objdir, "rt_capi.o"), host_cmd)
+    # only the entry points of include/rt_capi.h leave the library
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "rt_capi.map"), "-o", out, *objs])
     return out
+
+
+def build_host_library(force=False):
+    """The C++ host classes (csrc/host) behind flat entry points, for Python: links against the C-ABI library."""
+    srcs = [os.path.join(CSRC, "host", "harness.cpp"), os.path.join(CSRC, "host", "host_selftest.cpp")]
+    if not force and not _newer(HOST_LIB, _sources() + [LIB]):
+        return HOST_LIB
+    _run([HIPCC, "-x", "c++", *HOST_FLAGS, "-shared", *srcs, "-L" + PKG, "-lrt_gfx950", "-lz", "-Wl,-rpath,$ORIGIN", "-o", HOST_LIB])
+    return HOST_LIB
 
 
 def build_oracle(force=False):
@@ -104,6 +116,7 @@ def build_example(force=False):
 
 def build_all(force=False):
     build_library(force)
+    build_host_library(force)
     build_oracle(force)
     build_example(force)
 

@@ -944,8 +944,11 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams P, const in
                 base = __shfl(base, __ffsll((long long)m1) - 1, kWave);
                 const unsigned mine = nextStart + base + laneRank(m1) + laneRank(m2);
                 if (mine + (unsigned)want > (unsigned)P.nodeCap) {
-                    // no room: report, and fall back to the background so that nothing is read out of bounds
+                    // no room: report, and fall back to the background so that nothing is read out of bounds.
+                    // Requests are handed out in increasing order, so every later one fails too and at most one
+                    // request straddles the arrays' end: the slots below it are the level's last nodes.
                     atomicOr(P.ctl + CTL_OVERFLOW, 1u);
+                    if (mine < (unsigned)P.nodeCap) P.ctl[CTL_LEVEL_FIT + level + 1] = (mine - nextStart) + 1u;
                     const V3 c = (want == 1) ? muls(bg, kr) : add(muls(bg, kr), muls(bg, 1.0f - kr));
                     P.color[node] = make_float4(c.x, c.y, c.z, 0.0f);
                     P.kind[node] = NODE_DONE;
@@ -1061,14 +1064,28 @@ __global__ void __launch_bounds__(256) finalizeKernel(const FrameParams P) {
     }
 }
 
-// Opens `level`: fixes its first node and clears the per-level queues.
+// Opens `level`: fixes its first node and its node count, and clears the per-level queues.  Level 0 also clears the
+// rest of the control block (all but the sticky overflow word).  A level never holds more nodes than have a slot
+// AND a ray: requests that passed the arrays' end are dropped here (their parents took the background instead).
 __global__ void advanceKernel(const FrameParams P, const int level) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
     if (level == 0) {
-        P.ctl[CTL_LEVEL_START] = 0;
+        for (int w = threadIdx.x; w < CTL_WORDS; w += blockDim.x)
+            if (w != CTL_OVERFLOW) P.ctl[w] = 0u;
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    if (level == 0) {
         P.ctl[CTL_LEVEL_COUNT] = (unsigned)P.slots;
     } else {
-        P.ctl[CTL_LEVEL_START + level] = P.ctl[CTL_LEVEL_START + level - 1] + P.ctl[CTL_LEVEL_COUNT + level - 1];
+        const unsigned start = P.ctl[CTL_LEVEL_START + level - 1] + P.ctl[CTL_LEVEL_COUNT + level - 1];
+        const unsigned room = start < (unsigned)P.nodeCap ? (unsigned)P.nodeCap - start : 0u;
+        unsigned count = P.ctl[CTL_LEVEL_COUNT + level];
+        const unsigned fit = P.ctl[CTL_LEVEL_FIT + level];
+        if (count > room) count = room;
+        if (fit != 0u && count > fit - 1u) count = fit - 1u;
+        P.ctl[CTL_LEVEL_START + level] = start;
+        P.ctl[CTL_LEVEL_COUNT + level] = count;
     }
     P.ctl[CTL_TRACE_QUEUE] = 0;
     P.ctl[CTL_SHADOW_QUEUE] = 0;
@@ -1120,8 +1137,6 @@ int rtk_render_frame(const FrameParams* frame, int hasSecondary, int count, int 
     const int lastLevel = hasSecondary ? p.opts.maxDepth : 0;
     const dim3 wide(cuCount * 8), block(256);
     if (ev) (void)hipEventRecord(ev[0], s);
-    hipError_t e = hipMemsetAsync(p.ctl, 0, CTL_WORDS * sizeof(uint32_t), s);
-    if (e != hipSuccess) return (int)e;
     for (int level = 0; level <= lastLevel; ++level) {
         hipLaunchKernelGGL(advanceKernel, dim3(1), dim3(64), 0, s, p, level);
         if (count)

@@ -50,7 +50,9 @@ struct Workspace {
     void* vis = nullptr;
     void* stackSpill = nullptr;
     size_t spillBytes = 0;
+    size_t guardBytes = 0;  // guard band behind every array (rt_set_workspace_guards), filled with kGuardByte
 };
+constexpr int kGuardByte = 0xA5;
 
 // How meshes without BVH nodes get theirs on the device (rt_set_device_bvh).
 struct BuildParams {
@@ -97,6 +99,12 @@ struct rt_ctx {
     hipEvent_t stagingDone[2] = {nullptr, nullptr};
     hipStream_t copyStream = nullptr;
     std::string error;
+    size_t guardBytes = 0;  // rt_set_workspace_guards
+    // rt_render_noalloc: this device's copy of the library's static scratch array, and whether a frame that can
+    // overflow its path budget ran in it since the last rt_sync
+    unsigned char* scratch = nullptr;
+    size_t scratchBytes = 0;
+    bool scratchMayOverflow = false;
     // Events of the launches since the last rt_timing_reset.  At most kMaxTimedLaunches sets exist; a caller that
     // never resets keeps rendering, and the timing then covers the latest kMaxTimedLaunches launches.
     static constexpr size_t kMaxTimedLaunches = 4096;
@@ -487,18 +495,36 @@ void freeWorkspace(Workspace& w) {
     w = Workspace();
 }
 
+// The workspace's arrays and their sizes for `n` path nodes, `sc` of them beyond level 0, `lc` lights.
+struct WsArray {
+    void* Workspace::*member;
+    size_t bytes;
+    const char* name;
+};
+std::vector<WsArray> workspaceArrays(size_t n, size_t sc, size_t lc) {
+    return {{&Workspace::ctl, CTL_WORDS * sizeof(uint32_t), "ctl"}, {&Workspace::hit, n * 16, "hit"},
+            {&Workspace::hitTri, n * 4, "hitTri"},                  {&Workspace::color, n * 16, "color"},
+            {&Workspace::secRay, std::max<size_t>(sc * 32, 256), "secRay"}, {&Workspace::child, n * 4, "child"},
+            {&Workspace::kr, n * 4, "kr"},                          {&Workspace::kind, n * 4, "kind"},
+            {&Workspace::ctx, n * 64, "ctx"},                       {&Workspace::ctxNode, n * 4, "ctxNode"},
+            {&Workspace::vis, n * lc, "vis"}};
+}
+
 // Makes the workspace hold `nodeCap` path nodes (`slots` of them level 0) and `lights` lights.
 int ensureWorkspace(rt_ctx* ctx, Workspace& w, hipStream_t stream, int nodeCap, int slots, int lights, size_t spillBytes) {
     const int secCap = nodeCap - slots;
-    if (spillBytes > w.spillBytes) {
+    const size_t guard = ctx->guardBytes;
+    if (spillBytes > w.spillBytes || (guard != w.guardBytes && w.stackSpill)) {
         RT_HIP(ctx, hipStreamSynchronize(stream));
         if (w.stackSpill) hipFree(w.stackSpill);
         w.stackSpill = nullptr;
+        spillBytes = std::max(spillBytes, w.spillBytes);
         w.spillBytes = 0;
-        RT_HIP(ctx, hipMalloc(&w.stackSpill, spillBytes));
+        RT_HIP(ctx, hipMalloc(&w.stackSpill, spillBytes + guard));
+        if (guard) RT_HIP(ctx, fillNow(static_cast<unsigned char*>(w.stackSpill) + spillBytes, kGuardByte, guard, stream));
         w.spillBytes = spillBytes;
     }
-    if (w.ctl && nodeCap <= w.nodeCap && lights <= w.lightCap && secCap <= w.secCap) return RT_OK;
+    if (w.ctl && nodeCap <= w.nodeCap && lights <= w.lightCap && secCap <= w.secCap && guard == w.guardBytes) return RT_OK;
     RT_HIP(ctx, hipStreamSynchronize(stream));  // the slot's previous frame may still use the old arrays
     const int nc = std::max(nodeCap, w.nodeCap), lc = std::max(std::max(lights, 1), w.lightCap), sc = std::max(secCap, w.secCap);
     {
@@ -509,22 +535,15 @@ int ensureWorkspace(rt_ctx* ctx, Workspace& w, hipStream_t stream, int nodeCap, 
         w.stackSpill = keepSpill;
         w.spillBytes = keepBytes;
     }
-    const size_t n = (size_t)nc;
-    RT_HIP(ctx, hipMalloc(&w.ctl, CTL_WORDS * sizeof(uint32_t)));
+    for (const WsArray& a : workspaceArrays((size_t)nc, (size_t)sc, (size_t)lc)) {
+        RT_HIP(ctx, hipMalloc(&(w.*a.member), a.bytes + guard));
+        if (guard) RT_HIP(ctx, fillNow(static_cast<unsigned char*>(w.*a.member) + a.bytes, kGuardByte, guard, stream));
+    }
     RT_HIP(ctx, fillNow(w.ctl, 0, CTL_WORDS * sizeof(uint32_t), stream));
-    RT_HIP(ctx, hipMalloc(&w.hit, n * 16));
-    RT_HIP(ctx, hipMalloc(&w.hitTri, n * 4));
-    RT_HIP(ctx, hipMalloc(&w.color, n * 16));
-    RT_HIP(ctx, hipMalloc(&w.secRay, std::max<size_t>((size_t)sc * 32, 256)));
-    RT_HIP(ctx, hipMalloc(&w.child, n * 4));
-    RT_HIP(ctx, hipMalloc(&w.kr, n * 4));
-    RT_HIP(ctx, hipMalloc(&w.kind, n * 4));
-    RT_HIP(ctx, hipMalloc(&w.ctx, n * 64));
-    RT_HIP(ctx, hipMalloc(&w.ctxNode, n * 4));
-    RT_HIP(ctx, hipMalloc(&w.vis, n * (size_t)lc));
     w.nodeCap = nc;
     w.lightCap = lc;
     w.secCap = sc;
+    w.guardBytes = guard;
     return RT_OK;
 }
 
@@ -619,9 +638,21 @@ int rt_sync(rt_ctx* ctx) {
         // only frames that spawn child rays can run out of path nodes
         if (!sl.ws.ctl || !sl.mayOverflow) continue;
         sl.mayOverflow = false;
-        uint32_t block[CTL_WORDS];
-        RT_HIP(ctx, hipMemcpy(block, sl.ws.ctl, sizeof block, hipMemcpyDeviceToHost));
-        overflow |= block[CTL_OVERFLOW];
+        // the word is sticky on the device: it covers every frame the slot ran since the last rt_sync, and is cleared here
+        uint32_t word = 0;
+        uint32_t* dev = static_cast<uint32_t*>(sl.ws.ctl) + CTL_OVERFLOW;
+        RT_HIP(ctx, hipMemcpy(&word, dev, sizeof word, hipMemcpyDeviceToHost));
+        if (word) RT_HIP(ctx, fillNow(dev, 0, sizeof word, sl.lastStream ? sl.lastStream : ctx->stream));
+        overflow |= word;
+    }
+    if (ctx->scratchMayOverflow && ctx->scratch) {
+        ctx->scratchMayOverflow = false;
+        // rt_render_noalloc puts the control block first in the scratch array
+        uint32_t word = 0;
+        uint32_t* dev = reinterpret_cast<uint32_t*>(ctx->scratch) + CTL_OVERFLOW;
+        RT_HIP(ctx, hipMemcpy(&word, dev, sizeof word, hipMemcpyDeviceToHost));
+        if (word) RT_HIP(ctx, fillNow(dev, 0, sizeof word, ctx->stream));
+        overflow |= word;
     }
     if (overflow)
         return fail(ctx, RT_ERR_LIMIT, "reflection / refraction rays exceeded the path budget of %d x pixels; raise it with rt_set_path_budget",
@@ -674,6 +705,34 @@ int rt_set_lds_stack(rt_ctx* ctx, int entries) {
     if (!ctx) return RT_ERR_INVALID;
     if (entries < 1 || entries > RT_STACK_ENTRIES) return fail(ctx, RT_ERR_INVALID, "LDS stack entries must be in 1..%d", RT_STACK_ENTRIES);
     ctx->ldsStack = entries;
+    return RT_OK;
+}
+
+int rt_set_workspace_guards(rt_ctx* ctx, size_t bytes) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (bytes > (1u << 20) || bytes % 256 != 0) return fail(ctx, RT_ERR_INVALID, "guard size must be a multiple of 256 bytes, at most 1 MiB");
+    ctx->guardBytes = bytes;
+    return RT_OK;
+}
+
+int rt_check_workspace_guards(rt_ctx* ctx) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (int r = bind(ctx)) return r;
+    if (int r = syncFrames(ctx)) return r;
+    std::vector<unsigned char> host;
+    for (int si = 0; si < RT_MAX_FRAMES_IN_FLIGHT; ++si) {
+        Workspace& w = ctx->slots[si].ws;
+        if (!w.ctl || !w.guardBytes) continue;
+        std::vector<WsArray> arrays = workspaceArrays((size_t)w.nodeCap, (size_t)w.secCap, (size_t)w.lightCap);
+        arrays.push_back({&Workspace::stackSpill, w.spillBytes, "stackSpill"});
+        host.resize(w.guardBytes);
+        for (const WsArray& a : arrays) {
+            RT_HIP(ctx, hipMemcpy(host.data(), static_cast<unsigned char*>(w.*a.member) + a.bytes, w.guardBytes, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < host.size(); ++i)
+                if (host[i] != kGuardByte)
+                    return fail(ctx, RT_ERR_DEVICE, "workspace array '%s' of frame slot %d was written %zu bytes past its end", a.name, si, i);
+        }
+    }
     return RT_OK;
 }
 
@@ -907,9 +966,15 @@ void rt_device_free(rt_ctx* ctx, void* devPtr) {
     hipFree(devPtr);
 }
 
-int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCamera* cam, void* devSurface, size_t pitch,
-              int blockDim, const RtFrameAux* aux) {
-    (void)blockDim;
+}  // extern "C"
+
+namespace {
+
+// Body of rt_render and rt_render_noalloc.  `noAlloc`: the frame's workspace is carved from the device's static
+// scratch array, the frame runs on the context's stream, in order, with row-major tile order and without timing
+// events, and nothing on the way allocates or frees.
+int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCamera* cam, void* devSurface, size_t pitch,
+                const RtFrameAux* aux, bool noAlloc) {
     if (!ctx) return RT_ERR_INVALID;
     if (!scene || scene->ctx != ctx) return fail(ctx, RT_ERR_INVALID, "scene does not belong to this context");
     if (!opts || !cam || !devSurface) return fail(ctx, RT_ERR_INVALID, "null argument");
@@ -943,11 +1008,14 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     const int tileFirst = aux ? aux->tileFirst : 0;
     const int tileStride = aux && aux->tileStride > 0 ? aux->tileStride : 1;
     if (tileFirst < 0 || tileFirst >= tileStride) return fail(ctx, RT_ERR_INVALID, "tileFirst must be in [0, tileStride)");
-    const long long myTiles = (tiles - tileFirst + tileStride - 1) / tileStride;
-    if (myTiles <= 0) return RT_OK;
+    const long long myTiles = tileFirst < tiles ? (tiles - tileFirst + tileStride - 1) / tileStride : 0;
     const int secondary = hd.hasSecondary ? 1 : 0;
     const int budget = secondary && opts->maxDepth > 0 ? ctx->pathBudget : 1;
-    if (myTiles * RT_TILE * RT_TILE * budget * opts->samples > 0x7fffffffLL / 4) return fail(ctx, RT_ERR_LIMIT, "frame too large for 32-bit node indices");
+    const long long nodeCapWanted = myTiles * RT_TILE * RT_TILE * budget * opts->samples;
+    if (nodeCapWanted > 0x7fffffffLL / 4) return fail(ctx, RT_ERR_LIMIT, "frame too large for 32-bit node indices");
+    // shadow work items are (diffuse hit, light) pairs held in 32-bit signed indices
+    if (nodeCapWanted * std::max(hd.lightCnt, 1) > 0x7fffffffLL)
+        return fail(ctx, RT_ERR_LIMIT, "frame too large for 32-bit shadow-ray indices (%lld path nodes x %d lights)", nodeCapWanted, hd.lightCnt);
     p.stackEntries = hd.sceneDepth + hd.maxMeshDepth + 2;
     p.sceneRootRef = hd.sceneRootRef;
     p.offRecords = hd.offRecords;
@@ -973,6 +1041,49 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     p.sampleSeed = ctx->sampleSeed;
     p.nodeCap = p.slots * budget;
 
+    if (noAlloc) {
+        if (!ctx->scratch) return fail(ctx, RT_ERR_DEVICE, "the static scratch array is not available on device %d", ctx->device);
+        if (myTiles == 0) return RT_OK;
+        // Carve the workspace from the scratch array.  The traversal-stack spill area takes at most a quarter of it:
+        // fewer persistent wavefronts run when the scene's trees are deep.
+        const size_t perWave = (size_t)(p.stackEntries + RT_MESH_ENTRY_SLOTS) * 64 * 8;
+        const size_t spillMax = ctx->scratchBytes / 4;
+        if ((size_t)p.traceWaves * perWave > spillMax) p.traceWaves = (int)(spillMax / perWave);
+        if (p.traceWaves < 1) return fail(ctx, RT_ERR_LIMIT, "scratch array too small for one wavefront's traversal stack");
+        Workspace w;
+        size_t cursor = 0;
+        auto carve = [&](size_t bytes) {
+            unsigned char* at = ctx->scratch + cursor;
+            cursor = alignUp(cursor + bytes);
+            return static_cast<void*>(at);
+        };
+        for (const WsArray& a : workspaceArrays((size_t)p.nodeCap, (size_t)(p.nodeCap - p.slots), (size_t)std::max(hd.lightCnt, 1)))
+            w.*a.member = carve(a.bytes);
+        w.stackSpill = carve((size_t)p.traceWaves * perWave);
+        if (cursor > ctx->scratchBytes)
+            return fail(ctx, RT_ERR_LIMIT,
+                        "rt_render_noalloc: this call needs %zu bytes of workspace, the static scratch array holds %zu "
+                        "(%d path nodes, %d lights); render fewer tiles per call (RtFrameAux.tileStride) or use rt_render",
+                        cursor, ctx->scratchBytes, p.nodeCap, hd.lightCnt);
+        p.ctl = static_cast<uint32_t*>(w.ctl);
+        p.hit = static_cast<float4*>(w.hit);
+        p.hitTri = static_cast<int32_t*>(w.hitTri);
+        p.color = static_cast<float4*>(w.color);
+        p.secRay = static_cast<float4*>(w.secRay);
+        p.child = static_cast<int32_t*>(w.child);
+        p.kr = static_cast<float*>(w.kr);
+        p.kind = static_cast<int32_t*>(w.kind);
+        p.ctx = static_cast<float4*>(w.ctx);
+        p.ctxNode = static_cast<int32_t*>(w.ctxNode);
+        p.vis = static_cast<unsigned char*>(w.vis);
+        p.stackSpill = static_cast<uint2*>(w.stackSpill);
+        p.tileOrder = nullptr;  // row-major: an order table would have to be uploaded into fresh device memory
+        hipError_t e = (hipError_t)rtk_render_frame(&p, secondary, p.counters ? 1 : 0, ctx->cuCount, ctx->stream, nullptr);
+        if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
+        ctx->scratchMayOverflow = ctx->scratchMayOverflow || (secondary && opts->maxDepth > 0);
+        return RT_OK;
+    }
+
     // The frame's slot: with one frame in flight it runs on the context's stream, in order.  With
     // several, it runs on the slot's own stream behind everything enqueued on the context's
     // stream so far (and behind the slot's previous frame), and overlaps with the other slots.
@@ -985,6 +1096,20 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     }
     hipStream_t exec = forked ? sl.stream : ctx->stream;
     if (sl.issued && sl.lastStream && sl.lastStream != exec) RT_HIP(ctx, hipStreamWaitEvent(exec, sl.done, 0));
+
+    if (myTiles == 0) {
+        // A shard without tiles (more ranks than tiles): nothing to launch, but the call still counts as a frame, so
+        // that rt_stream_wait_frame(framesAgo) keeps meaning "that many rt_render calls ago" on every rank.
+        if (forked) {
+            RT_HIP(ctx, hipEventRecord(sl.ready, ctx->stream));
+            RT_HIP(ctx, hipStreamWaitEvent(exec, sl.ready, 0));
+        }
+        RT_HIP(ctx, hipEventRecord(sl.done, exec));
+        sl.issued = true;
+        sl.lastStream = exec;
+        ctx->frameCounter++;
+        return RT_OK;
+    }
 
     const size_t spillBytes = (size_t)p.traceWaves * (size_t)(p.stackEntries + RT_MESH_ENTRY_SLOTS) * 64 * 8;
     if (int r = ensureWorkspace(ctx, sl.ws, sl.lastStream ? sl.lastStream : exec, p.nodeCap, p.slots, hd.lightCnt, std::max<size_t>(spillBytes, 256))) return r;
@@ -1064,6 +1189,16 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
     ctx->frameCounter++;
     ctx->launchesUsed++;
     return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCamera* cam, void* devSurface, size_t pitch,
+              int blockDim, const RtFrameAux* aux) {
+    (void)blockDim;
+    return renderFrame(ctx, scene, opts, cam, devSurface, pitch, aux, false);
 }
 
 int rt_timing_reset(rt_ctx* ctx) {

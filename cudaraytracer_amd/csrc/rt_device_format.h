@@ -36,6 +36,7 @@
 #ifndef RT_DEVICE_FORMAT_H
 #define RT_DEVICE_FORMAT_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/rt_capi.h"
@@ -136,14 +137,17 @@ static_assert(sizeof(TriRecord) == 48, "TriRecord size");
 #endif
 
 // ---- frame workspace ------------------------------------------------------
-// Control block (uint32 words in device memory, zeroed at frame start).
+// Control block (uint32 words in device memory).  Every word except CTL_OVERFLOW is cleared when a frame opens
+// its first level; CTL_OVERFLOW stays set until rt_sync has reported it.
 enum {
     CTL_TRACE_QUEUE = 0,   // head of the closest-hit work queue of the current level
     CTL_SHADOW_QUEUE = 1,  // head of the shadow-ray work queue of the current level
     CTL_DIFFUSE_CNT = 2,   // diffuse hits of the current level
-    CTL_OVERFLOW = 3,      // set when a child ray did not fit the node arrays
     CTL_LEVEL_START = 8,   // [RT_MAX_DEPTH + 2] first node of each level
-    CTL_LEVEL_COUNT = 40,  // [RT_MAX_DEPTH + 2] nodes of each level
+    CTL_LEVEL_COUNT = 40,  // [RT_MAX_DEPTH + 2] nodes of each level: while the level above is shaded, the slots its
+                           // child rays ASKED for (may pass the arrays' end); once the level is opened, the nodes it holds
+    CTL_LEVEL_FIT = 72,    // [RT_MAX_DEPTH + 2] 1 + the level's nodes below a request that straddled the arrays' end (0 = none did)
+    CTL_OVERFLOW = 127,    // sticky: a child ray did not fit the node arrays
     CTL_WORDS = 128
 };
 

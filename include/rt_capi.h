@@ -302,8 +302,15 @@ int rt_timing_read_stages(rt_ctx* ctx, double* totalMs, double* stageMs, int* la
 
 /* Mirror / glass materials spawn child rays (cudaTracer/tracer.cu:117-142); the
  * per-frame node arrays hold `nodesPerPixel` x pixels path nodes (default 3).
- * A frame that needs more reports RT_ERR_LIMIT from rt_sync. */
+ * A frame that needs more drops the child rays that do not fit (their parents take the background colour for
+ * them) and the next rt_sync returns RT_ERR_LIMIT, however many frames were rendered in between. */
 int rt_set_path_budget(rt_ctx* ctx, int nodesPerPixel);
+
+/* Diagnostic: every workspace array allocated from now on gets `bytes` (a multiple of 256, 0 = none) of guard
+ * band behind it, filled with a pattern; rt_check_workspace_guards waits for the frames in flight and returns
+ * RT_ERR_DEVICE naming the array if a kernel wrote past an array's end.  The reference has no counterpart. */
+int rt_set_workspace_guards(rt_ctx* ctx, size_t bytes);
+int rt_check_workspace_guards(rt_ctx* ctx);
 
 /* Mesh BVHs built on the device.  A mesh handed to rt_scene_upload with nodes == NULL and nodeCnt == 0 gets its
  * BVH built on the GPU with the algorithm of cudaTracer/BVH.h:104-181 (median cut of the box centroids along the

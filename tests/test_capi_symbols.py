@@ -28,6 +28,15 @@ def test_header_symbols_are_exported_and_bound():
         assert s in syms, f"{s} bound in Python but not declared in rt_capi.h"
 
 
+def test_library_exports_only_the_declared_entry_points():
+    """The shipped library carries no test scaffolding: its dynamic symbol table is exactly include/rt_capi.h."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", N.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == declared_symbols()
+
+
 def test_struct_sizes_match_reference_layouts():
     # sizes measured from the reference's headers (LP64): Vertex 56, LinearNode 32, Triangle 12,
     # Light 28, Material 32, DeviceOpts 48

@@ -294,6 +294,83 @@ def test_path_budget_overflow_is_reported(gpu_ctx):
     gpu_ctx.render_frame(scene)  # the context stays usable
 
 
+def test_path_budget_overflow_stays_inside_the_workspace(oracle):
+    """Budget 1 with glass at depth 6: every level asks for more nodes than the arrays hold.  No array may be written
+    past its end (guard bands behind each one stay intact), the nodes that fit are traced like the oracle's, and the
+    flag survives later frames on the same slot until rt_sync reports it."""
+    w, h = 128, 96
+    scene = rt.HostScene("mixed", w, h, 0, 2, 6)
+    ok = rt.HostScene("cubes", w, h, 3, 1, 0)
+    ctx = rt.Context(0)
+    try:
+        ctx.set_workspace_guards(4096)
+        ctx.set_path_budget(1)
+        dscene, dok = ctx.upload(scene), ctx.upload(ok)
+        surf, pitch = ctx.surface(w, h)
+        for frames in (1, 3):
+            ctx.set_frames_in_flight(frames)
+            for _ in range(frames):
+                ctx.render(dscene, scene.opts, scene.camera, surf, pitch)
+            # frames that do not overflow, on the same slots, before anybody syncs
+            for _ in range(2 * frames):
+                ctx.render(dok, ok.opts, ok.camera, surf, pitch)
+            with pytest.raises(rt.RtError, match="budget"):
+                ctx.sync()
+            ctx.sync()  # reported once
+            ctx.check_workspace_guards()
+        # level 0 fits: pixels whose primary hit is diffuse do not depend on the dropped children
+        ctx.set_frames_in_flight(1)
+        keys = ctx.alloc(w * h * 16)
+        ctx.render(dscene, scene.opts, scene.camera, surf, pitch, keys)
+        with pytest.raises(rt.RtError, match="budget"):
+            ctx.sync()
+        rgba = ctx.download_surface(surf, pitch, w, h)
+        got_keys = ctx.download(keys, (h, w, 4), np.int32)
+        ref_rgba, ref_keys, _ = oracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=8, shadow_any_hit=True)
+        assert (got_keys == ref_keys).all()
+        from parity import compare
+
+        assert compare(rgba, None, ref_rgba, None)["radiance_ok_fraction"] > 0.5  # the diffuse part of the image
+        ctx.check_workspace_guards()
+    finally:
+        ctx.close()
+
+
+def test_frame_limits_are_checked_before_launch(gpu_ctx):
+    """Shadow work items are (hit, light) pairs in 32-bit indices: a frame whose path nodes x lights pass 2^31 is
+    refused.  (The surface is large enough for the frame, so the call is valid in every other respect.)"""
+    w = h = 2048
+    scene = rt.HostScene("soup", w, h, 1000, 16, 0)
+    assert scene.desc.contents.lightCnt == 16
+    dscene = gpu_ctx.upload(scene)
+    surf, pitch = gpu_ctx.surface(w, h)
+    scene.opts.contents.samples = 64  # 2^28 path nodes x 16 lights = 2^32
+    try:
+        with pytest.raises(rt.RtError, match="32-bit shadow-ray indices"):
+            gpu_ctx.render(dscene, scene.opts, scene.camera, surf, pitch)
+    finally:
+        gpu_ctx.free(surf)
+        gpu_ctx.free_scene(dscene)
+
+
+def test_empty_tile_shard_counts_as_a_frame(gpu_ctx):
+    """More ranks than tiles: a call without tiles launches nothing but keeps rt_stream_wait_frame's frame count."""
+    scene = rt.HostScene("cubes", 16, 8, 2, 1, 0)  # 2 tiles
+    dscene = gpu_ctx.upload(scene)
+    surf, pitch = gpu_ctx.surface(16, 8)
+    try:
+        gpu_ctx.set_frames_in_flight(2)
+        gpu_ctx.render(dscene, scene.opts, scene.camera, surf, pitch, None, None, 1, 4)  # tile 1
+        gpu_ctx.render(dscene, scene.opts, scene.camera, surf, pitch, None, None, 3, 4)  # no tile
+        gpu_ctx.stream_wait_frame(None, 0)
+        gpu_ctx.stream_wait_frame(None, 1)
+        gpu_ctx.sync()
+    finally:
+        gpu_ctx.set_frames_in_flight(1)
+        gpu_ctx.free(surf)
+        gpu_ctx.free_scene(dscene)
+
+
 def test_bad_render_arguments(gpu_ctx):
     scene = rt.HostScene("cubes", 64, 48, 3, 1, 0)
     dscene = gpu_ctx.upload(scene)
