@@ -271,6 +271,12 @@ class Context:
         o = opts.contents if hasattr(opts, "contents") else opts
         self._check(self.lib.rt_render(self.ctx, scene, C.byref(o), camera, surf, pitch, o.blockSize, C.byref(aux)), "rt_render")
 
+    def render_noalloc(self, scene, opts, camera, surf, pitch, hit_keys=None, counters=None, tile_first=0, tile_stride=1):
+        """rt_render_noalloc: same frame, workspace from the library's static device scratch array, no allocation."""
+        aux = N.RtFrameAux(hit_keys, counters, tile_first, tile_stride)
+        o = opts.contents if hasattr(opts, "contents") else opts
+        self._check(self.lib.rt_render_noalloc(self.ctx, scene, C.byref(o), camera, surf, pitch, o.blockSize, C.byref(aux)), "rt_render_noalloc")
+
     def sync(self):
         self._check(self.lib.rt_sync(self.ctx), "rt_sync")
 

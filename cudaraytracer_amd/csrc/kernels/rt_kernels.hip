@@ -1129,6 +1129,20 @@ int rtk_trace_waves_per_cu(int stackLds) {
     return w;
 }
 
+// Workspace of rt_render_noalloc: one array per GPU the library runs on, held until the process ends.  In host
+// code the array's name only stands for the symbol; its address on the current device comes from
+// hipGetSymbolAddress and is what kernels and memory calls are given.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+
+int rtk_scratch(void** devPtr, size_t* bytes) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return (int)e;
+    *devPtr = p;
+    *bytes = sizeof(scratch);
+    return 0;
+}
+
 // Enqueues the kernel sequence of one frame on `stream`.
 int rtk_render_frame(const FrameParams* frame, int hasSecondary, int count, int cuCount, void* stream, void** stageEvents) {
     const FrameParams& p = *frame;

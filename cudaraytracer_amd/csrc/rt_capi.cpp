@@ -594,6 +594,17 @@ rt_ctx* rt_create(int device) {
     }
     ctx->cuCount = prop.multiProcessorCount;
     ctx->stream = ctx->ownStream;
+    // this device's copy of the static scratch array (rt_render_noalloc); looked up once, with the device current
+    void* scratch = nullptr;
+    size_t scratchBytes = 0;
+    const int se = rtk_scratch(&scratch, &scratchBytes);
+    if (se == 0) {
+        ctx->scratch = static_cast<unsigned char*>(scratch);
+        ctx->scratchBytes = scratchBytes;
+    } else {
+        // only rt_render_noalloc needs it, and says so when called
+        fail(ctx, RT_ERR_DEVICE, "hipGetSymbolAddress(scratch) on device %d: %s", device, hipGetErrorString((hipError_t)se));
+    }
     return ctx;
 }
 
@@ -1199,6 +1210,12 @@ int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCa
               int blockDim, const RtFrameAux* aux) {
     (void)blockDim;
     return renderFrame(ctx, scene, opts, cam, devSurface, pitch, aux, false);
+}
+
+int rt_render_noalloc(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCamera* cam, void* devSurface, size_t pitch,
+                      int blockDim, const RtFrameAux* aux) {
+    (void)blockDim;
+    return renderFrame(ctx, scene, opts, cam, devSurface, pitch, aux, true);
 }
 
 int rt_timing_reset(rt_ctx* ctx) {

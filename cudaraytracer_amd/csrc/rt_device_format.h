@@ -229,6 +229,10 @@ struct RtBvhBuildJob {
 // centroids all coincide (the reference makes such a range one big leaf; build that mesh on the host).
 int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* stream, int* degenerate);
 
+// Device address and size of the CURRENT device's copy of the library's static scratch array (the workspace of
+// rt_render_noalloc).  Returns a hipError_t value.
+int rtk_scratch(void** devPtr, size_t* bytes);
+
 // Resident wavefronts per CU of the trace kernels for a given LDS stack size.
 int rtk_trace_waves_per_cu(int stackLds);
 

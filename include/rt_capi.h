@@ -290,6 +290,22 @@ void rt_device_free(rt_ctx* ctx, void* devPtr);
 int rt_render(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCamera* cam,
               void* devSurface, size_t pitch, int blockDim, const RtFrameAux* aux);
 
+/* rt_render for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments, same pixels; the
+ * differences:
+ *   - the frame's workspace (path-node arrays, shading contexts, visibility bytes, traversal-stack spill area,
+ *     control block) is carved from a static device array of RT_NOALLOC_SCRATCH_BYTES that every GPU the library
+ *     runs on holds until the process ends; a call that needs more fails with RT_ERR_LIMIT and says how much
+ *     (about 120 bytes + one per light per path node: a 640x480 frame with 4 lights fits; render larger frames in
+ *     several calls with RtFrameAux.tileStride);
+ *   - it runs on the context's stream, in order, whatever rt_set_frames_in_flight says, takes the tiles in row-major
+ *     order, records no timing events, and calls no hipMalloc / hipFree or any other allocating routine;
+ *   - every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two contexts, two streams) race;
+ *     calls on one stream are ordered and safe.  Nothing in the array needs to survive between calls. */
+#define RT_NOALLOC_SCRATCH_BYTES (64u << 20)
+int rt_render_noalloc(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const RtCamera* cam,
+                      void* devSurface, size_t pitch, int blockDim, const RtFrameAux* aux);
+
 /* HIP-event timing of the rt_render calls since the last reset, measured on the
  * stream they ran on.  Call after rt_sync.  totalMs sums the whole per-frame
  * kernel sequence; stageMs[4] (may be NULL) splits it into: closest-hit trace of
