@@ -376,6 +376,25 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     int hShape = -1, hTri = -1;
     float hu = 0.0f, hv = 0.0f;
 
+#ifdef RT_STAMPS  // diagnostic build: shader-clock cycles per section of the loop, summed per wavefront (COUNT launches only)
+    unsigned stampAcc[16] = {}, stampCnt[16] = {};
+    unsigned long long stampLast = __builtin_amdgcn_s_memtime();
+#define STAMP(i)                                                          \
+    do {                                                                  \
+        if (COUNT) {                                                      \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+            stampAcc[i] += (unsigned)(now_ - stampLast);                  \
+            stampCnt[i] += 1u;                                            \
+            stampLast = now_;                                             \
+        }                                                                 \
+    } while (0)
+#else
+#define STAMP(i) \
+    do {         \
+    } while (0)
+#endif
+
     auto push = [&](unsigned x, unsigned y) {
         if (sp - lo >= ringN) {
             gstk[(size_t)lo * kWave] = stk[(lo & ringMask) * kWave];
@@ -469,6 +488,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
             continue;
         }
 
+        STAMP(0);  // refill
         // ---- advance the rays until enough lanes have finished --------------
         while (true) {
             const unsigned long long nodeMask = __ballot((int)cur >= 0);
@@ -484,6 +504,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     wTailLanes += nb;
                 }
             }
+            STAMP(1);  // vote
             if (triPhase) {
                 // ================= cooperative triangle phase =================
                 const bool isTri = (cur >> 30) == 2u;
@@ -501,6 +522,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     if (ANY) tBuf[rank] = tMax;  // a shadow ray's reach never shrinks: the testing lanes can apply it themselves
                 }
                 __syncthreads();
+                STAMP(4);  // triangle phase: rays published
                 const int rounds = (nPart + 7) >> 3;
                 // ANY: lanes whose triangle the ray accepts, per round (bit = lane: 8 bits per participating ray)
                 unsigned long long accepted[kTriPart / 8] = {};
@@ -517,6 +539,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                         const float4* rec = records + 3 * (size_t)idx;
                         const float4 r0 = rec[0], r1 = rec[1];
                         const float e2z = reinterpret_cast<const float*>(rec + 2)[0];
+                        STAMP(5);  // triangle phase: records arrived
                         float tt, uu, vv;
                         if (triangleSolve(r0, r1, e2z, mk(A.x, A.y, A.z), mk(B.x, B.y, B.z), tt, uu, vv)) {
                             solved = true;
@@ -536,6 +559,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     }
                 }
                 if (!ANY) __syncthreads();
+                STAMP(6);  // triangle phase: tests done, results in LDS
                 if (part) {
                     int win = -1;
                     if (ANY) {
@@ -571,6 +595,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     const unsigned nn = next + 8u;
                     cur = (ANY && win >= 0) ? CUR_DONE : (nn >= end ? CUR_POP : (TAG_TRI | nn));
                 }
+                STAMP(7);  // triangle phase: results applied
             } else if (nodeMask != 0ull) {
                 // ========================= node step ==========================
                 if (COUNT) {
@@ -580,6 +605,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                 if ((int)cur >= 0) {
                     const float4* p = blob4 + ((size_t)RT_REF_PAIR_UNITS(cur) << 2);
                     const float4 L0 = p[0], L1 = p[1], L2 = p[2], L3 = p[3];
+                    STAMP(2);  // node step: child pair arrived
                     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
                     float t0, t1;
                     bool g0, g1;
@@ -613,6 +639,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     enter(nearRef);
                     if (!nearHit) cur = CUR_POP;
                 }
+                STAMP(3);  // node step: boxes tested, far child pushed
             }
             // ================= scene-leaf shapes (per lane) ==================
             if (cur >= TAG_SHAPE && cur < STACK_MESH_EXIT) {
@@ -652,6 +679,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     end = m->recordBase + (unsigned)m->triangleCnt;
                 }
             }
+            STAMP(8);  // scene-leaf shapes
             // ========================= stack pops ============================
             RT_POP_WHILE (cur == CUR_POP) {
                 if (sp == 0) {
@@ -674,6 +702,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     }
                 }
             }
+            STAMP(9);  // pops
             // keep going while most lanes still work; once the queue is dry, until all are done
             const unsigned long long busy = __ballot(cur != CUR_DONE);
             if (busy == 0ull) break;
@@ -692,9 +721,17 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
             }
             item = -1;
         }
+        STAMP(10);  // results published
     }
 
     if (COUNT && P.counters) {
+#ifdef RT_STAMPS
+        if (lane == 0)
+            for (int i = 0; i < 16; ++i) {
+                atomicAdd(P.counters + 64 + (ANY ? 32 : 0) + 2 * i, (unsigned long long)stampAcc[i]);
+                atomicAdd(P.counters + 64 + (ANY ? 32 : 0) + 2 * i + 1, (unsigned long long)stampCnt[i]);
+            }
+#endif
         unsigned vals[6] = {cNode, cTri, cSphere, cMesh, cRays, cPrimary};
         const int where[6] = {RT_CNT_NODE, RT_CNT_TRI, RT_CNT_SPHERE, RT_CNT_MESH_ENTRY,
                               ANY ? RT_CNT_SHADOW : (level > 0 ? RT_CNT_SECONDARY : -1), ANY ? -1 : RT_CNT_PRIMARY};

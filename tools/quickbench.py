@@ -64,7 +64,7 @@ with rt.Context(0) as ctx:
     print(f"second upload: {time.time()-t:.3f}s", flush=True)
     ctx.free_scene(ds2)
     surf, pitch = ctx.surface(a.width, a.height)
-    cnt = ctx.alloc(rt.RT_COUNTER_CNT * 8)
+    cnt = ctx.alloc(rt.RT_COUNTER_CNT * 8 * 8)  # room for the diagnostic build's section stamps
     ctx.render(ds, scene.opts, scene.camera, surf, pitch, None, cnt)
     ctx.sync()
     import numpy as np
@@ -76,6 +76,16 @@ with rt.Context(0) as ctx:
             tl = [int(v) for v in raw[28 + (0 if name == "closest" else 2):30 + (0 if name == "closest" else 2)]]
             print(f"  {name}: tail {100.0*tl[0]/st[0]:.1f}% of the wave-steps with {tl[1]/max(tl[0],1):.1f} lanes; before it {(st[5]-tl[1])/max(st[0]-tl[0],1):.1f} lanes")
             print(f"  {name}: wave-steps {st[0]}  node-steps {st[1]} (avg lanes {st[2]/max(st[1],1):.1f})  tri-steps {st[3]} (avg lanes {st[4]/max(st[3],1):.1f})  avg lanes with a ray {st[5]/st[0]:.1f}")
+    if os.environ.get("RT_STAMPS"):  # a library built with -DRT_STAMPS: cycles per loop section, summed over wavefronts
+        big = ctx.download(cnt, (128,), np.uint64)
+        names = ["refill", "vote", "node: wait for pair", "node: math + push", "tri: publish", "tri: wait for records", "tri: math + store",
+                 "tri: apply", "shapes", "pops", "publish"]
+        for kname, base in (("closest", 64), ("shadow", 96)):
+            tot = sum(int(big[base + 2 * i]) for i in range(16))
+            print(f"  {kname}: {tot/1e6:.1f} M cycles in all wavefronts")
+            for i, n in enumerate(names):
+                cyc, k = int(big[base + 2 * i]), int(big[base + 2 * i + 1])
+                print(f"    {n:24s} {100.0*cyc/max(tot,1):5.1f} %  {k:9d} times  {cyc/max(k,1):8.1f} cycles each")
     rays = c["primary"] + c["shadow"] + c["secondary"]
     nf = max(a.frames_in_flight, 1)
     surfs = [surf] + [ctx.surface(a.width, a.height)[0] for _ in range(nf - 1)]
