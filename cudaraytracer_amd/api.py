@@ -325,6 +325,10 @@ class Context:
         """1 = frames run in order on the context's stream; 2..8 = consecutive frames overlap on internal streams."""
         self._check(self.lib.rt_set_frames_in_flight(self.ctx, frames), "rt_set_frames_in_flight")
 
+    def set_arithmetic(self, fast):
+        """False = exact (bit-identical to the reference's formulas), True = the fast build of the kernels."""
+        self._check(self.lib.rt_set_arithmetic(self.ctx, 1 if fast else 0), "rt_set_arithmetic")
+
     def stream_wait_frame(self, stream_ptr=None, frames_ago=0):
         self._check(self.lib.rt_stream_wait_frame(self.ctx, stream_ptr, frames_ago), "rt_stream_wait_frame")
 

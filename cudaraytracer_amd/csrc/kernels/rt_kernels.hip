@@ -23,12 +23,36 @@
 // compiled with -ffp-contract=off, IEEE division and square root, denormals on,
 // so hit decisions are bit-identical to a host evaluation of the same formulas.
 // Only powf (gamma, Blinn-Phong) may differ in the last ulp.
+//
+// The file is compiled a second time with -DRT_FAST=1, contraction to fused
+// multiply-adds and approximate division / square root: the FAST build, whose
+// entry points carry the suffix _fast.  It keeps the algorithm, the visiting
+// order and the tie rule, but not the roundings: its results are held to the
+// tolerance of the parity tests (hit keys on >= 99.99 % of the pixels, radiance
+// within 1e-4 relative or one 8-bit step) instead of bit equality.  What decides
+// WHICH primitive a ray hits stays exact there too (primary ray
+// directions, reciprocal directions, the triangle and sphere tests, the change to
+// a mesh's object space), because scenes are full of exact ties - rays through a
+// shared edge of two triangles, coplanar faces of neighbouring boxes - that any
+// change of rounding resolves differently.  Measured on the 16 x 16 cube grid
+// at 640 x 480 with a contracted triangle test: 128 pixels (0.04 %) change their
+// hit key, all of them on cube edges.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 
 #include "../rt_device_format.h"
+
+#ifdef RT_FAST
+#define RTK(name) name##_fast
+#else
+#define RTK(name) name
+#endif
+
+// Everything from here to the shading section keeps the reference's roundings in BOTH builds: vector helpers, ray
+// set-up, box / triangle / sphere tests and the trace kernel.
+#pragma clang fp contract(off)
 
 namespace {
 
@@ -64,7 +88,11 @@ __device__ __forceinline__ V3 muls(V3 a, float r) { return mk(a.x * r, a.y * r, 
 __device__ __forceinline__ V3 divs(V3 a, float r) { return mk(a.x / r, a.y / r, a.z / r); }
 __device__ __forceinline__ V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
 // cudaTracer/Vec.cuh:232-238: the sum starts at 0 (keeps the sign-of-zero behaviour)
+#if defined(RT_FAST) && !defined(RT_KEEP_ZERO)
+__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+#else
 __device__ __forceinline__ float dot(V3 a, V3 b) { return ((0.0f + a.x * b.x) + a.y * b.y) + a.z * b.z; }
+#endif
 // cudaTracer/Vec.cuh:240-247
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
@@ -90,50 +118,66 @@ __device__ __forceinline__ unsigned laneRank(unsigned long long mask) {
 }
 
 // ---------------------------------------------------------------------------
-// cudaTracer/BoundingBox.cuh:115-139 on the two boxes of a sibling pair at once, split in two: everything that
-// does not depend on the ray's current reach (slab overlap and "far plane in front of the origin") comes back
-// as ok0 / ok1, the entry distances as tMin0 / tMin1; a box is visited iff  ok && tMin < ray.tMax  - the
-// reference's final expression.  Records: n0 = {min.x, min.y, min.z, max.x}, n1 = {max.y, max.z, ref, -} for the
-// first box, n2 / n3 likewise for the second.  Each plane distance of the first box shares a two-wide
-// operation with the matching one of the second box; every value is formed by the reference's sequence of
-// roundings.  The far planes of x and y are padded by 1 + 2*gamma(3) == 1 + 3*2^-23 in fp32, z is not.
-typedef float F2 __attribute__((ext_vector_type(2)));
+// cudaTracer/BoundingBox.cuh:115-139, literally, split in two: everything that does not depend on the ray's current
+// reach (slab overlap and "far plane in front of the origin") comes back as `ok`, the entry distance as tMin; a box
+// is visited iff  ok && tMin < ray.tMax  - the reference's final expression.  A box is {min.x, min.y, min.z, max.x},
+// {max.y, max.z}; every value is formed by the reference's sequence of roundings.  The far planes of x and y are
+// padded by 1 + 2*gamma(3) == 1 + 3*2^-23 in fp32, z is not.
+__device__ __forceinline__ void boxLiteral(const float4 lo, const float hiY, const float hiZ, const V3 o, const V3 inv, const bool nx, const bool ny,
+                                           const bool nz, bool& okOut, float& tMinOut) {
+    constexpr float kPad = 0x1.000006p+0f;
+    float tMin = ((nx ? lo.w : lo.x) - o.x) * inv.x;
+    float tMax = (((nx ? lo.x : lo.w) - o.x) * inv.x) * kPad;
+    const float tyMin = ((ny ? hiY : lo.y) - o.y) * inv.y;
+    const float tyMax = (((ny ? lo.y : hiY) - o.y) * inv.y) * kPad;
+    bool ok = !(tMin > tyMax || tyMin > tMax);
+    if (tyMin > tMin) tMin = tyMin;
+    if (tyMax < tMax) tMax = tyMax;
+    const float tzMin = ((nz ? hiZ : lo.z) - o.z) * inv.z;
+    const float tzMax = ((nz ? lo.z : hiZ) - o.z) * inv.z;
+    ok = ok && !(tMin > tzMax || tzMin > tMax);
+    if (tzMin > tMin) tMin = tzMin;
+    if (tzMax < tMax) tMax = tzMax;
+    tMinOut = tMin;
+    okOut = ok && (tMax > 0);
+}
 __device__ __forceinline__ void boxPairSlabs(const float4 n0, const float4 n1, const float4 n2, const float4 n3, const V3 o, const V3 inv,
                                              const bool nx, const bool ny, const bool nz, bool& ok0, bool& ok1, float& tMin0, float& tMin1) {
-    constexpr float kPad = 0x1.000006p+0f;
-    const F2 xn = {nx ? n0.w : n0.x, nx ? n2.w : n2.x}, xf = {nx ? n0.x : n0.w, nx ? n2.x : n2.w};
-    const F2 yn = {ny ? n1.x : n0.y, ny ? n3.x : n2.y}, yf = {ny ? n0.y : n1.x, ny ? n2.y : n3.x};
-    const F2 zn = {nz ? n1.y : n0.z, nz ? n3.y : n2.z}, zf = {nz ? n0.z : n1.y, nz ? n2.z : n3.y};
-    const F2 txMin = (xn - o.x) * inv.x;
-    const F2 txMax = ((xf - o.x) * inv.x) * kPad;
-    const F2 tyMin = (yn - o.y) * inv.y;
-    const F2 tyMax = ((yf - o.y) * inv.y) * kPad;
-    const F2 tzMin = (zn - o.z) * inv.z;
-    const F2 tzMax = (zf - o.z) * inv.z;
-    {
-        float tMin = txMin.x, tMax = txMax.x;
-        bool ok = !(tMin > tyMax.x || tyMin.x > tMax);
-        if (tyMin.x > tMin) tMin = tyMin.x;
-        if (tyMax.x < tMax) tMax = tyMax.x;
-        ok = ok && !(tMin > tzMax.x || tzMin.x > tMax);
-        if (tzMin.x > tMin) tMin = tzMin.x;
-        if (tzMax.x < tMax) tMax = tzMax.x;
-        tMin0 = tMin;
-        ok0 = ok && (tMax > 0);
-    }
-    {
-        float tMin = txMin.y, tMax = txMax.y;
-        bool ok = !(tMin > tyMax.y || tyMin.y > tMax);
-        if (tyMin.y > tMin) tMin = tyMin.y;
-        if (tyMax.y < tMax) tMax = tyMax.y;
-        ok = ok && !(tMin > tzMax.y || tzMin.y > tMax);
-        if (tzMin.y > tMin) tMin = tzMin.y;
-        if (tzMax.y < tMax) tMax = tzMax.y;
-        tMin1 = tMin;
-        ok1 = ok && (tMax > 0);
-    }
+    boxLiteral(n0, n1.x, n1.y, o, inv, nx, ny, nz, ok0, tMin0);
+    boxLiteral(n2, n3.x, n3.y, o, inv, nx, ny, nz, ok1, tMin1);
 }
 
+// The FAST build's form of the same test: near / far plane distance = the smaller / larger of the two plane distances
+// of an axis, and "largest entry <= smallest exit" for the reference's chain of comparisons.  It agrees with the
+// literal form whenever no plane distance is a NaN (finite ray origin, reciprocal direction finite and free of zeros)
+// and the boxes have min <= max: then (min - o) <= (max - o), a product with inv keeps or reverses that order, and the
+// smaller product is the reference's near-plane distance, formed by the same operations; the reference's comparisons
+// say "every entry <= every exit of ANOTHER axis", and entry <= exit of the SAME axis can only fail when a padded exit
+// distance is negative, where the box fails "exit > 0" in both forms.  A ray lying exactly in a box face (0 * inf) can
+// come out differently.  In the EXACT build this form bought nothing: with the literal form beside it for such rays
+// the kernel needs more registers than it saves instructions (measured: 1615 against 1625-1650 Mrays/s).
+__device__ __forceinline__ void boxPairMinMax(const float4 n0, const float4 n1, const float4 n2, const float4 n3, const V3 o, const V3 inv,
+                                              bool& ok0, bool& ok1, float& tMin0, float& tMin1) {
+    constexpr float kPad = 0x1.000006p+0f;
+    {
+        const float ax = (n0.x - o.x) * inv.x, bx = (n0.w - o.x) * inv.x;
+        const float ay = (n0.y - o.y) * inv.y, by = (n1.x - o.y) * inv.y;
+        const float az = (n0.z - o.z) * inv.z, bz = (n1.y - o.z) * inv.z;
+        const float tMin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        const float tMax = fminf(fminf(fmaxf(ax, bx) * kPad, fmaxf(ay, by) * kPad), fmaxf(az, bz));
+        tMin0 = tMin;
+        ok0 = tMin <= tMax && tMax > 0.0f;
+    }
+    {
+        const float ax = (n2.x - o.x) * inv.x, bx = (n2.w - o.x) * inv.x;
+        const float ay = (n2.y - o.y) * inv.y, by = (n3.x - o.y) * inv.y;
+        const float az = (n2.z - o.z) * inv.z, bz = (n3.y - o.z) * inv.z;
+        const float tMin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        const float tMax = fminf(fminf(fmaxf(ax, bx) * kPad, fmaxf(ay, by) * kPad), fmaxf(az, bz));
+        tMin1 = tMin;
+        ok1 = tMin <= tMax && tMax > 0.0f;
+    }
+}
 // cudaTracer/Sphere.cuh:9-54
 __device__ __forceinline__ bool sphereHit(const DevShape& s, const V3 o, const V3 d, float& tMax) {
     const V3 L = sub(o, mk(s.center));
@@ -609,7 +653,11 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
                     float t0, t1;
                     bool g0, g1;
+#ifdef RT_FAST
+                    boxPairMinMax(L0, L1, L2, L3, o, inv, g0, g1, t0, t1);
+#else
                     boxPairSlabs(L0, L1, L2, L3, o, inv, nx, ny, nz, g0, g1, t0, t1);
+#endif
                     const unsigned axis = RT_REF_AXIS(cur);
                     const bool single = axis == RT_REF_ROOT_AXIS;  // a root record: there is no sibling
                     // cudaTracer/Mesh.cuh:155-161: with a negative direction along the split axis the
@@ -694,7 +742,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                         o = mk(__uint_as_float(e0.x), __uint_as_float(e0.y), __uint_as_float(e1.x));
                         d = mk(__uint_as_float(e1.y), __uint_as_float(e2.x), __uint_as_float(e2.y));
                         inv = mk(__uint_as_float(e3.x), __uint_as_float(e3.y), __uint_as_float(e4.x));
-                        end = c.y;
+                            end = c.y;
                         cur = (c.x & IDX_MASK) < c.y ? c.x : CUR_POP;
                     } else {
                         if (COUNT) cNode++;
@@ -757,6 +805,12 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
 }
 
 // ---------------------------------------------------------------------------
+// Shading.  The FAST build contracts the expressions written in this section (texture filtering, interpolation,
+// Fresnel, the light sums); the vector helpers above keep their roundings.
+#ifdef RT_FAST
+#pragma clang fp contract(fast)
+#endif
+
 // cudaTracer/Texture.cuh:50-69.  WRAP wraps negative indices into range (the
 // reference's C '%' leaves them negative and reads out of bounds).
 __device__ __forceinline__ V3 texel(const unsigned char* __restrict__ data, int w, int h, int mode, int x, int y) {
@@ -777,14 +831,23 @@ __device__ __forceinline__ V3 texel(const unsigned char* __restrict__ data, int 
 // cudaTracer/Texture.cuh:33-48: texel-centre offset and the two "1 - ratio"
 // weights go through double; every weight is rounded to float before it scales a colour.
 __device__ __forceinline__ V3 texSample(const unsigned char* __restrict__ data, int w, int h, int mode, float u, float v) {
+#ifdef RT_FAST
+    u = u * (float)w - 0.5f;
+    v = v * (float)h - 0.5f;
+#else
     u = (float)((double)(u * (float)w) - 0.5);
     v = (float)((double)(v * (float)h) - 0.5);
+#endif
     const int x = (int)floorf(u);
     const int y = (int)floorf(v);
     const float ur = u - (float)x;
     const float vr = v - (float)y;
+#ifdef RT_FAST
+    const float uo = 1.0f - ur, vo = 1.0f - vr;
+#else
     const float uo = (float)(1.0 - (double)ur);
     const float vo = (float)(1.0 - (double)vr);
+#endif
     const V3 top = add(muls(texel(data, w, h, mode, x, y), uo), muls(texel(data, w, h, mode, x + 1, y), ur));
     const V3 bot = add(muls(texel(data, w, h, mode, x, y + 1), uo), muls(texel(data, w, h, mode, x + 1, y + 1), ur));
     return add(muls(top, vo), muls(bot, vr));
@@ -1156,7 +1219,7 @@ void launchTrace(const FrameParams& p, int level, int cuCount, hipStream_t s) {
 
 }  // namespace
 
-int rtk_trace_waves_per_cu(int stackLds) {
+int RTK(rtk_trace_waves_per_cu)(int stackLds) {
     const size_t lds = traceLdsBytes(stackLds);
     // the largest residency of the four variants: each launch takes its own, this one sizes the spill buffer
     int w = wavesPerCu<false, false>(lds);
@@ -1166,6 +1229,7 @@ int rtk_trace_waves_per_cu(int stackLds) {
     return w;
 }
 
+#ifndef RT_FAST
 // Workspace of rt_render_noalloc: one array per GPU the library runs on, held until the process ends.  In host
 // code the array's name only stands for the symbol; its address on the current device comes from
 // hipGetSymbolAddress and is what kernels and memory calls are given.
@@ -1180,8 +1244,10 @@ int rtk_scratch(void** devPtr, size_t* bytes) {
     return 0;
 }
 
+#endif
+
 // Enqueues the kernel sequence of one frame on `stream`.
-int rtk_render_frame(const FrameParams* frame, int hasSecondary, int count, int cuCount, void* stream, void** stageEvents) {
+int RTK(rtk_render_frame)(const FrameParams* frame, int hasSecondary, int count, int cuCount, void* stream, void** stageEvents) {
     const FrameParams& p = *frame;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t* ev = reinterpret_cast<hipEvent_t*>(stageEvents);

@@ -322,6 +322,20 @@ int rt_timing_read_stages(rt_ctx* ctx, double* totalMs, double* stageMs, int* la
  * them) and the next rt_sync returns RT_ERR_LIMIT, however many frames were rendered in between. */
 int rt_set_path_budget(rt_ctx* ctx, int nodesPerPixel);
 
+/* Arithmetic of the render kernels.
+ *   RT_ARITHMETIC_EXACT (default): every fp32 operation of the trace / shade path in the reference's operation
+ *     order, no fused multiply-adds, IEEE division and square root: hit decisions and radiance are bit-identical to
+ *     a host evaluation of the reference's formulas (cudaTracer/tracer.cu, Mesh.cuh, Sphere.cuh, BoundingBox.cuh).
+ *   RT_ARITHMETIC_FAST: the same kernels compiled with contraction to fused multiply-adds, approximate division and
+ *     square root, the box test folded into min / max form and fp32 texture weights.  Same algorithm, visiting order
+ *     and tie rule; results agree with EXACT within the parity tolerance (hit keys on >= 99.99 % of the pixels,
+ *     radiance within 1e-4 relative or one 8-bit step), not bit for bit.  Rays grazing a triangle edge or lying in
+ *     a box face may resolve differently.
+ * The reference has one build (nvcc's default contracts to FMA, cudaTracer/cudaTracer.vcxproj). */
+#define RT_ARITHMETIC_EXACT 0
+#define RT_ARITHMETIC_FAST 1
+int rt_set_arithmetic(rt_ctx* ctx, int mode);
+
 /* Diagnostic: every workspace array allocated from now on gets `bytes` (a multiple of 256, 0 = none) of guard
  * band behind it, filled with a pattern; rt_check_workspace_guards waits for the frames in flight and returns
  * RT_ERR_DEVICE naming the array if a kernel wrote past an array's end.  The reference has no counterpart. */

@@ -25,6 +25,7 @@ ap.add_argument("--reference-bvh", action="store_true")
 ap.add_argument("--lds-stack", type=int, default=0)
 ap.add_argument("--frames-in-flight", type=int, default=0)
 ap.add_argument("--waves", type=int, default=0)
+ap.add_argument("--fast", action="store_true", help="the FAST build of the kernels (rt_set_arithmetic)")
 ap.add_argument("--tile-order", type=int, default=-1)
 ap.add_argument("--device-bvh", action="store_true")
 ap.add_argument("--assets", default=None, help="asset directory for the mixed / barrel scenes; 'synthetic' writes stand-ins to a temp dir")
@@ -46,6 +47,8 @@ print(f"scene {a.scene} size {a.size}: built in {time.time()-t:.2f}s, depth {sce
 with rt.Context(0) as ctx:
     if a.waves:
         ctx.set_trace_waves(a.waves)
+    if a.fast:
+        ctx.set_arithmetic(True)
     if a.tile_order >= 0:
         ctx.set_tile_order(a.tile_order)
     if a.frames_in_flight:
