@@ -6,10 +6,15 @@ random soup, on N MI355X of one node.
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 A step is one full 1920x1080 frame through rt_render (the C-ABI).  With N > 1
-the scene blob is broadcast once over RCCL, every rank renders the 8x8 tiles
+the scene blob is shared once over RCCL, every rank renders the 8x8 tiles
 t = rank, rank+N, ... of the same frame, and the tiles are gathered to rank 0
 inside the timed region (strong scaling: the frame is fixed, the work per GPU
 shrinks).  Rank 0 prints ONE JSON line.
+
+`value` is measured with the EXACT build of the kernels (bit-identical to the
+reference's formulas) and frames in flight; the same line carries the strictly
+in-order figure, the FAST build, the other workloads of the scope table, the
+roofline of the dominant kernel and the CPU baseline.
 """
 import os
 
@@ -31,15 +36,11 @@ sys.path.insert(0, ROOT)
 import cudaraytracer_amd as rt  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
-FP32_VECTOR_PEAK_TFLOPS = 256 * 128 * 2 * 2.4e9 / 1e12  # 256 CUs x 128 fp32 lanes x FMA at 2.4 GHz
-NODE_BYTES, TRI_BYTES, SPHERE_BYTES, MESH_ENTRY_BYTES = 32, 48, 20, 64
-SHADE_MESH_BYTES, SHADE_SPHERE_BYTES, PIXEL_BYTES = 216, 32, 16
-
-
-def algorithmic_bytes(cnt, pixels):
-    """Bytes the traversal must touch: per test / per shaded hit / per pixel figures x the kernel's exact test counts."""
-    return (NODE_BYTES * cnt["node"] + TRI_BYTES * cnt["tri"] + SPHERE_BYTES * cnt["sphere"] + MESH_ENTRY_BYTES * cnt["mesh_entry"] +
-            SHADE_MESH_BYTES * cnt["shade_mesh"] + SHADE_SPHERE_BYTES * cnt["shade_sphere"] + PIXEL_BYTES * pixels)
+FP32_VECTOR_PEAK_TFLOPS = 256 * 4 * 32 * 2 * 2.4e9 / 1e12  # 256 CUs x 4 SIMDs x 32 fp32 lanes x 2 (FMA) at 2.4 GHz = 157.3
+# algorithmic work per test (the survey's per-unit figures)
+NODE_FLOPS, TRI_FLOPS, SPHERE_FLOPS, MESH_ENTRY_FLOPS = 24, 60, 30, 31
+HIT_RECORD_BYTES = 20  # float4 {t, u, v, shape} + int triangle, written per traced path node
+PROFILE_ROUND = "r02"
 
 
 def parse():
@@ -56,9 +57,34 @@ def parse():
     ap.add_argument("--reference-bvh", action="store_true", help="build BVHs with the reference's FLT_MIN-clamped boxes")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="skip the other workloads and the FAST build (headline only)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="consecutive frames that may overlap on a GPU (1 = strictly in order, at most 16; default 12)")
     return ap.parse_args()
+
+
+def host_threads():
+    """Threads for the CPU baseline: every CPU this process may run on, within the share the box grants a job
+    (OMP_NUM_THREADS is set to that share on a shared machine)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    grant = os.environ.get("OMP_NUM_THREADS", "")
+    if grant.isdigit() and int(grant) > 0:
+        n = min(n, int(grant))
+    return max(1, n)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(scene, args):
@@ -67,7 +93,7 @@ def cpu_baseline(scene, args):
     of the same source where the CPU can run it.  `value` is the faster of the two."""
     from oracle import pyoracle
 
-    threads = max(1, min(16, os.cpu_count() or 1))
+    threads = host_threads()
     w, h = args.width, args.height
     builds = [("-O2 -ffp-contract=off", False)]
     if pyoracle.o3_supported():
@@ -85,13 +111,16 @@ def cpu_baseline(scene, args):
         figures.append((rays / dt / 1e6, flags, frames, rays, dt))
     best = max(figures)
     return {"value": best[0], "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "host_logical_cpus": os.cpu_count(), "cpu_model": cpu_model(),
             "builds": {f[1]: round(f[0], 3) for f in figures},
             "sample": "; ".join(f"{f[2]} full {w}x{h} frame(s) of the same scene ({f[3]} rays, {f[4]:.1f} s) with gcc {f[1]}" for f in figures) +
-                      f"; rows interleaved over {threads} threads, any-hit shadow rays, same BVH as the GPU run; value = the faster build"}
+                      f"; rows interleaved over {threads} threads (every CPU this job is granted; the machine has {os.cpu_count()} "
+                      "logical CPUs, shared with other jobs), any-hit shadow rays, same BVH as the GPU run; value = the faster build"}
 
 
-def pmc_table(workload_key):
-    """Per-kernel figures of the committed PMC passes for this workload (profiles/traffic.json), or {}."""
+def profile_table(workload_key):
+    """Per-kernel figures of the committed PMC passes for this workload (profiles/traffic.json), or {}.  These are
+    constants measured in an earlier, separate rocprofv3 run of this script - not measurements of the run that prints them."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         return json.load(open(path)).get(workload_key, {})
@@ -99,21 +128,89 @@ def pmc_table(workload_key):
         return {}
 
 
-def pmc_traffic(kernel, workload_key):
-    """HBM bytes per launch of `kernel` from the committed PMC passes, or None."""
-    entry = pmc_table(workload_key).get(kernel)
-    return None if entry is None else entry.get("hbm_bytes_per_launch")
+def counters_of(ctx, dscene, opts, camera_ref, surface_ptr, pitch, rank=0, world=1):
+    """One untimed frame with the counter build of the kernels: exact ray / test counts and the wave statistics."""
+    import torch
+
+    cnt_buf = torch.zeros(rt.RT_COUNTER_CNT, dtype=torch.int64, device=torch.device("cuda", torch.cuda.current_device()))
+    ctx.render(dscene, opts, camera_ref, surface_ptr, pitch, None, cnt_buf.data_ptr(), rank, world)
+    ctx.sync()
+    torch.cuda.synchronize()
+    return cnt_buf
 
 
-def pmc_valu_issue_fraction(workload_key, ms_per_step, cu_count=256, clock_hz=2.4e9):
-    """Share of the SIMDs' issue cycles that the frame's vector instructions take: every launch of a frame (SQ_INSTS_VALU
-    of the committed PMC pass, 4 cycles per wavefront-wide instruction) over 4 SIMDs x CUs x clock x frame time."""
-    table = pmc_table(workload_key)
-    frame_kernels = ["traceKernel<false, false>", "traceKernel<true, false>", "shadeKernel<false>", "accumKernel", "finalizeKernel"]
-    insts = [table.get(k, {}).get("valu_insts_per_launch") for k in frame_kernels]
-    if any(v is None for v in insts[:2]) or ms_per_step <= 0:
-        return None
-    return 4.0 * sum(v for v in insts if v) / (4 * cu_count * clock_hz * ms_per_step * 1e-3)
+def wave_statistics(raw):
+    """Lane use of the two trace kernels, from the counter build's own statistics (measured in this run)."""
+    out = {}
+    for name, base, tail in (("trace_closest", 16, 28), ("trace_shadow", 22, 30)):
+        steps, node_steps, node_lanes, tri_steps, tri_rays, busy = (int(v) for v in raw[base:base + 6])
+        tail_steps, tail_lanes = int(raw[tail]), int(raw[tail + 1])
+        if steps == 0:
+            continue
+        out[name] = {
+            "wave_steps": steps,
+            "node_steps": node_steps, "lanes_per_node_step": node_lanes / max(node_steps, 1),
+            "triangle_phases": tri_steps, "rays_per_triangle_phase_of_16": tri_rays / max(tri_steps, 1),
+            "lanes_holding_a_ray": busy / steps,
+            "steps_after_queue_ran_dry": tail_steps / steps,
+            "lanes_holding_a_ray_after_queue_ran_dry": tail_lanes / max(tail_steps, 1),
+        }
+    return out
+
+
+def time_frames(ctx, render, frames, in_flight, surfaces):
+    """(wall ms per frame, HIP-event ms per frame [frame, closest, shade, shadow, rest]) of `frames` calls of render(surface)."""
+    import torch
+
+    ctx.sync()
+    ctx.set_frames_in_flight(in_flight)
+    for i in range(max(in_flight, 2)):  # every slot gets its stream and workspace before anything is timed
+        render(surfaces[i % len(surfaces)])
+    ctx.sync()
+    ctx.timing_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(frames):
+        render(surfaces[i % len(surfaces)])
+    ctx.sync()
+    wall = (time.perf_counter() - t0) / frames * 1e3
+    k_ms, st, n = ctx.timing_read_stages()
+    n = max(n, 1)
+    return wall, [k_ms / n] + [x / n for x in st]
+
+
+def other_workload(ctx, torch, dev, label, scene_args, scene_kwargs, nf):
+    """In-order and in-flight figures of another workload of the scope table, on the same kernels."""
+    t0 = time.perf_counter()
+    scene = rt.HostScene(*scene_args, **scene_kwargs)
+    build_s = time.perf_counter() - t0
+    w, h = scene.width, scene.height
+    t0 = time.perf_counter()
+    dscene = ctx.upload(scene)
+    ctx.sync()
+    upload_s = time.perf_counter() - t0
+    surfaces = [torch.zeros((h, w, 4), dtype=torch.float32, device=dev) for _ in range(nf)]
+    pitch = w * 16
+    opts, cam = scene.opts.contents, scene.camera
+    raw = counters_of(ctx, dscene, opts, cam, surfaces[0].data_ptr(), pitch).tolist()
+    cnt = dict(zip(rt.RT_COUNTER_NAMES, raw))
+    rays = cnt["primary"] + cnt["shadow"] + cnt["secondary"]
+
+    def render(s):
+        ctx.render(dscene, opts, cam, s.data_ptr(), pitch)
+
+    wall1, ev1 = time_frames(ctx, render, 10, 1, surfaces)
+    walln, _ = time_frames(ctx, render, 3 * nf, nf, surfaces)
+    ctx.set_frames_in_flight(1)
+    ctx.free_scene(dscene)
+    scene.close()
+    del surfaces
+    torch.cuda.empty_cache()
+    return {"workload": label, "rays_per_frame": rays, "primary": cnt["primary"], "shadow": cnt["shadow"], "secondary": cnt["secondary"],
+            "box_tests_per_ray": cnt["node"] / max(rays, 1), "triangle_tests_per_ray": cnt["tri"] / max(rays, 1),
+            "in_order_ms_per_frame": ev1[0], "in_order_Mrays_per_s": rays / wall1 / 1e3,
+            "in_flight_ms_per_frame": walln, "in_flight_Mrays_per_s": rays / walln / 1e3, "frames_in_flight": nf,
+            "scene_build_s": round(build_s, 2), "upload_s": round(upload_s, 2)}
 
 
 def main():
@@ -153,7 +250,7 @@ def main():
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
 
-    # ---- scene: built on rank 0 by the C++ host API, broadcast as one blob ----
+    # ---- scene: built on rank 0 by the C++ host API, shared as one blob ----
     scene = None
     t_build = time.perf_counter()
     if rank == 0:
@@ -169,7 +266,7 @@ def main():
             cam = scene.camera.contents
             cam0 = list(cam.orig) + list(cam.camera)
         blob, opts_raw, cam_f = mg.share_scene(blob0, opts0, cam0, rank, world, comm_dev)  # RCCL over xGMI: scene + BVH, once
-        blob = blob.to(dev)
+        blob = blob.to(dev).contiguous()
         torch.cuda.synchronize(dev)
         dscene = ctx.adopt_blob(blob.data_ptr(), blob.numel())
         opts = rt.RtDeviceOpts.from_buffer_copy(opts_raw)
@@ -213,73 +310,80 @@ def main():
         issued[0] = 0
 
     # ---- exact ray / test counts of the frame (untimed counter build) ----
-    cnt_buf = torch.zeros(rt.RT_COUNTER_CNT, dtype=torch.int64, device=dev)
-    ctx.render(dscene, opts, camera_ref, surface.data_ptr(), pitch, None, cnt_buf.data_ptr(), rank, world)
-    torch.cuda.synchronize(dev)
+    cnt_buf = counters_of(ctx, dscene, opts, camera_ref, surface.data_ptr(), pitch, rank, world)
     if multi:
         cnt_buf = cnt_buf.to(comm_dev)
         dist.all_reduce(cnt_buf)
     cnt = {name: int(cnt_buf[i].item()) for i, name in enumerate(rt.RT_COUNTER_NAMES)}
     rays = cnt["primary"] + cnt["shadow"]
 
-    ctx.sync()
-    ctx.set_frames_in_flight(nf)
-    # set-up, not warm-up: one frame per slot, so that every frame in flight has its stream and workspace (a few ms of
-    # allocations each) before anything is timed, whatever --warmup says
-    for _ in range(nf):
-        step()
-    drain()
-    ctx.sync()
-    for _ in range(args.warmup):
-        step()
-    drain()
-    ctx.sync()
-    torch.cuda.synchronize(dev)
-    ctx.timing_reset()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    issue_s = time.perf_counter() - t0  # host time to enqueue the frames (and their gathers); the GPU may lag behind
-    drain()
-    ctx.sync()
-    torch.cuda.synchronize(dev)
-    if multi:
-        dist.barrier()
+    def timed_region(steps, warmup):
+        """The contract's timed region: `warmup` untimed steps, then exactly `steps` steps between barriers."""
+        ctx.sync()
+        ctx.set_frames_in_flight(nf)
+        # set-up, not warm-up: one frame per slot, so that every frame in flight has its stream and workspace (a few ms of
+        # allocations each) before anything is timed, whatever --warmup says
+        for _ in range(nf):
+            step()
+        drain()
+        ctx.sync()
+        for _ in range(warmup):
+            step()
+        drain()
+        ctx.sync()
         torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    kernel_ms, stages, launches = ctx.timing_read_stages()
-    launches = max(launches, 1)
-    # per-stage averages measured with HIP events on the library's stream: [closest-hit trace, shade, shadow trace, rest]
-    t_stage = [kernel_ms / launches] + [x / launches for x in stages]
-    if multi:
-        t = torch.tensor([elapsed, issue_s] + t_stage, dtype=torch.float64, device=comm_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, issue_s, t_stage = float(t[0].item()), float(t[1].item()), [float(x) for x in t[2:].tolist()]
-    frame_ms, closest_ms, shade_ms, shadow_ms, rest_ms = t_stage
+        ctx.timing_reset()
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        issue_s = time.perf_counter() - t0  # host time to enqueue the frames (and their gathers); the GPU may lag behind
+        drain()
+        ctx.sync()
+        torch.cuda.synchronize(dev)
+        if multi:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        kernel_ms, stages, launches = ctx.timing_read_stages()
+        launches = max(launches, 1)
+        # per-stage averages measured with HIP events on the library's stream: [frame, closest-hit trace, shade, shadow trace, rest]
+        t_stage = [kernel_ms / launches] + [x / launches for x in stages]
+        if multi:
+            t = torch.tensor([elapsed, issue_s] + t_stage, dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, issue_s, t_stage = float(t[0].item()), float(t[1].item()), [float(x) for x in t[2:].tolist()]
+        return elapsed, issue_s, t_stage
 
-    # ---- the kernels on their own (untimed for `value`): with frames in flight a launch shares the GPU with the
-    # neighbouring frames' kernels and its start-to-end time says little about the kernel itself, so the roofline
-    # uses launches that run alone, one frame at a time - the state a rocprofv3 kernel trace of
-    # `bench.py --frames-in-flight 1` records.
-    alone = t_stage
-    if nf > 1:
+    def alone(frames=10):
+        """The kernels on their own: one frame in flight, strictly in order - the state a rocprofv3 kernel trace of
+        `bench.py --frames-in-flight 1` records.  Returns per-frame HIP-event averages [frame, closest, shade, shadow, rest]
+        and the wall time per frame."""
+        ctx.sync()
         ctx.set_frames_in_flight(1)
         for _ in range(2):
             ctx.render(dscene, opts, camera_ref, surfaces[0].data_ptr(), pitch, None, None, rank, world)
         ctx.sync()
         ctx.timing_reset()
-        for _ in range(10):
+        t0 = time.perf_counter()
+        for _ in range(frames):
             ctx.render(dscene, opts, camera_ref, surfaces[0].data_ptr(), pitch, None, None, rank, world)
         ctx.sync()
+        wall = (time.perf_counter() - t0) / frames * 1e3
         k_ms, st, n = ctx.timing_read_stages()
-        alone = [k_ms / max(n, 1)] + [x / max(n, 1) for x in st]
+        out = [k_ms / max(n, 1)] + [x / max(n, 1) for x in st] + [wall]
         if multi:
-            t = torch.tensor(alone, dtype=torch.float64, device=comm_dev)
+            t = torch.tensor(out, dtype=torch.float64, device=comm_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            alone = [float(x) for x in t.tolist()]
+            out = [float(x) for x in t.tolist()]
+        return out[:5], out[5]
+
+    # ================= the timed region (EXACT build) =================
+    elapsed, issue_s, in_flight_stage = timed_region(args.steps, args.warmup)
+    alone_stage, alone_wall = alone() if nf > 1 else (in_flight_stage, elapsed / args.steps * 1e3)
+
     # ---- the gathered frame against the same frame rendered whole on rank 0 (untimed) ----
     gather_check = None
     if multi and rank == 0:
@@ -290,24 +394,90 @@ def main():
         a, b = gatherer.assembled().to(dev), whole
         differing = int(((a != b) & ~(torch.isnan(a) & torch.isnan(b))).any(dim=2).sum().item())
         gather_check = "identical to the frame rendered whole on GPU 0" if differing == 0 else f"{differing} pixels differ from the frame rendered whole on GPU 0"
-    in_flight_ms = {"frame": frame_ms, "trace_closest": closest_ms, "shade": shade_ms, "trace_shadow": shadow_ms, "rest": rest_ms}
-    frame_ms, closest_ms, shade_ms, shadow_ms, rest_ms = alone
 
+    # ================= the FAST build on the same workload (untimed for `value`) =================
+    fast = None
+    if not args.no_others:
+        exact_keys = torch.zeros((h, w, 4), dtype=torch.int32, device=dev)
+        fast_keys = torch.zeros((h, w, 4), dtype=torch.int32, device=dev)
+        exact_frame = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+        ctx.set_frames_in_flight(1)
+        ctx.render(dscene, opts, camera_ref, exact_frame.data_ptr(), pitch, exact_keys.data_ptr(), None, rank, world)
+        ctx.sync()
+        ctx.set_arithmetic(True)
+        ctx.render(dscene, opts, camera_ref, surfaces[0].data_ptr(), pitch, fast_keys.data_ptr(), None, rank, world)
+        ctx.sync()
+        torch.cuda.synchronize(dev)
+        f_elapsed, _, _ = timed_region(max(args.steps // 2, 10), 2)
+        f_steps = max(args.steps // 2, 10)
+        f_alone, f_alone_wall = alone()
+        ctx.set_arithmetic(False)
+        if rank == 0:
+            a, b = surfaces[0], exact_frame  # the last fast frame and the exact frame
+            same_key = (exact_keys == fast_keys).all(dim=2)
+            both_nan = torch.isnan(a) & torch.isnan(b)
+            rel = ((a - b).abs() / b.abs().clamp_min(1e-12)).masked_fill(both_nan, 0.0)
+            lsb = ((a * 256).nan_to_num(0.0).clamp(0, 255).floor() - (b * 256).nan_to_num(0.0).clamp(0, 255).floor()).abs()
+            ok = ((rel <= 1e-4) | (lsb <= 1)).all(dim=2)
+            fast = {"value": rays * f_steps / f_elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": f_elapsed / f_steps * 1e3,
+                    "in_order_ms_per_frame": f_alone[0], "in_order_Mrays_per_s": rays / f_alone_wall / 1e3,
+                    "hit_key_agreement_with_exact_build": float(same_key.float().mean().item()) if world == 1 else None,
+                    "radiance_within_tolerance_fraction": float(ok.float().mean().item()) if world == 1 else None,
+                    "note": "rt_set_arithmetic(FAST): min / max box test, shading contracted to fused multiply-adds, fp32 texture "
+                            "weights; everything that decides which primitive a ray hits keeps the exact arithmetic. Tolerance: hit keys "
+                            ">= 99.99 %, radiance 1e-4 relative or one 8-bit step (tests/test_gpu_fast_build.py holds it against the oracle)"}
+        del exact_keys, fast_keys, exact_frame
+
+    # ================= other workloads of the scope table (untimed for `value`, one GPU) =================
+    others = []
+    if not args.no_others and not multi:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import tempfile
+
+        import synth_assets
+
+        ctx.free_scene(dscene)
+        dscene = None
+        assets = synth_assets.write_assets(tempfile.mkdtemp(prefix="rt_assets_"))
+        plans = [
+            ("cfg 2 on the reference's own BVH: the same soup with FLT_MIN-clamped boxes (cudaTracer/BoundingBox.cuh:25-27)",
+             ("soup", w, h, args.size, args.lights, args.max_depth), {"tight_bvh": False}),
+            ("cfg 1: 16x16 grid of cube meshes (one mesh BVH each) under a scene BVH, 640x480, 4 lights, maxDepth 5",
+             ("cubes", 640, 480, 16, 4, 5), {"tight_bvh": True}),
+            ("cfg 3: OBJ barrel (488 triangles, three 1024x1024 maps) in three instances, one a mirror, textured plane, mirror and "
+             "glass balls, 1920x1080, 10 lights, maxDepth 2 (stand-in asset files of the reference's shape)",
+             ("barrel", 1920, 1080, 0, 10, 2), {"asset_dir": assets, "tight_bvh": True}),
+            ("cfg 4: height field of 9 999 392 triangles in one mesh BVH built on the device, 3840x2160, 1 light",
+             ("heightfield", 3840, 2160, 10000000, 1, 0), {"tight_bvh": True, "device_bvh": True}),
+            ("cfg 5: default-scene analogue (sphere field, mirror and glass balls, textured plane, three mesh instances), "
+             "1920x1080, 16 lights, maxDepth 4",
+             ("mixed", 1920, 1080, 0, 16, 4), {"asset_dir": assets, "tight_bvh": True}),
+        ]
+        for label, a, kw in plans:
+            try:
+                others.append(other_workload(ctx, torch, dev, label, a, kw, nf))
+            except Exception as e:  # a workload that cannot run is reported, the headline stays
+                others.append({"workload": label, "error": str(e)})
+
+    frame_ms, closest_ms, shade_ms, shadow_ms, rest_ms = alone_stage
     if rank == 0:
         raw = [int(x) for x in cnt_buf.tolist()]
         sh = dict(zip(("node", "tri", "sphere", "mesh_entry"), raw[9:13]))
         closest = {k: cnt[k] - sh[k] for k in sh}
-        # algorithmic bytes of the dominant launch: the closest-hit trace of the primary rays (one launch per frame
-        # when maxDepth is 0) reads 32 B per box test, 48 B per triangle test, 20 B per sphere test, 64 B per mesh
-        # entry, and writes 20 B of hit record per ray; with N GPUs one launch handles 1/N of the frame
-        closest_bytes = (NODE_BYTES * closest["node"] + TRI_BYTES * closest["tri"] + SPHERE_BYTES * closest["sphere"] +
-                         MESH_ENTRY_BYTES * closest["mesh_entry"] + 20 * (cnt["primary"] + cnt["secondary"]))
-        shadow_bytes = (NODE_BYTES * sh["node"] + TRI_BYTES * sh["tri"] + SPHERE_BYTES * sh["sphere"] + MESH_ENTRY_BYTES * sh["mesh_entry"] +
-                        (64 + 1) * cnt["shadow"])
-        frame_bytes = algorithmic_bytes(cnt, w * h)
-        gbs = lambda b, ms: b / world / (ms * 1e-3) / 1e9 if ms > 0 else None
-        achieved = gbs(closest_bytes, closest_ms)
+        traced = cnt["primary"] + cnt["secondary"]
+        flops = lambda c: NODE_FLOPS * c["node"] + TRI_FLOPS * c["tri"] + SPHERE_FLOPS * c["sphere"] + MESH_ENTRY_FLOPS * c["mesh_entry"]
+        closest_flops, shadow_flops = flops(closest), flops(sh)
+        tflops = lambda f, ms: f / world / (ms * 1e-3) / 1e12 if ms > 0 else None
+        achieved = tflops(closest_flops, closest_ms)
+        # compulsory HBM bytes of the closest-hit launch: the BVH nodes and triangle records it walks, read once, and the
+        # hit records it writes; everything else it touches again comes from L2 / Infinity Cache by construction
+        d = scene.desc.contents
+        bvh_bytes = 32 * d.nodeCnt + 64 * d.shapeCnt + sum(32 * d.meshes[i].nodeCnt + 48 * d.meshes[i].triangleCnt for i in range(d.meshCnt))
+        compulsory = bvh_bytes + HIT_RECORD_BYTES * traced // world
         wl_key = f"{args.scene}-{args.size}-{w}x{h}-l{args.lights}-d{args.max_depth}"
+        prof = profile_table(wl_key).get("traceKernel<false, false>", {}) if world == 1 else {}
+        prof_src = f"profiles/traffic.json <- profiles/{PROFILE_ROUND}: separate rocprofv3 --pmc passes of `bench.py --frames-in-flight 1`, NOT this run"
+        ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": "Mrays/s (primary+shadow) at 1080p, 1M tris",
             "value": rays * args.steps / elapsed / 1e6,
@@ -315,7 +485,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": ms_per_step,
             "host_issue_ms_per_step": issue_s / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
@@ -324,45 +494,53 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.scene}: {args.size} random triangles in one mesh BVH, {w}x{h}, {args.lights} light(s), "
                                    f"primary + shadow rays, samples 1, maxDepth {args.max_depth}, "
-                                   f"{'reference (FLT_MIN-clamped)' if args.reference_bvh else 'tight-bounds'} median-split BVH",
+                                   f"{'reference (FLT_MIN-clamped)' if args.reference_bvh else 'tight-bounds'} median-split BVH; "
+                                   "EXACT build of the kernels (bit-identical to the reference's formulas)",
                        "rays_per_frame": rays, "primary": cnt["primary"], "shadow": cnt["shadow"],
                        "tile_sharding": f"8x8 tiles, tile t on GPU t % {world}, gathered to GPU0 each frame" if multi else "single GPU",
                        "frames_in_flight": nf,
+                       "frame_latency_ms_with_frames_in_flight": in_flight_stage[0],
+                       "in_order": {"ms_per_frame": frame_ms, "wall_ms_per_frame": alone_wall, "Mrays_per_s": rays / alone_wall / 1e3,
+                                    "note": "one frame in flight: every frame starts after the previous one has finished, as the reference's "
+                                            "cudamain + cudaDeviceSynchronize does; `value` overlaps consecutive frames instead"},
                        "gathered_frame": gather_check,
-                       "scene_build_s": round(t_build, 2)},
+                       "scene_build_s": round(t_build, 2),
+                       "other_workloads": others},
             "kernel_ms": {"frame": frame_ms, "trace_closest": closest_ms, "shade": shade_ms, "trace_shadow": shadow_ms, "rest": rest_ms,
-                          "note": "launches running alone (one frame in flight), measured after the timed region"},
-            "kernel_ms_in_flight": in_flight_ms,
-            "roofline": {"bound": "hbm", "kernel": "traceKernel<false,false> (closest hit, primary rays)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic("traceKernel<false, false>", wl_key) if world == 1 else None,
-                         "algorithmic_bytes_per_launch": closest_bytes // world,
-                         "other_kernels": {"traceKernel<true,false> (shadow, any hit)": {"achieved": gbs(shadow_bytes, shadow_ms),
-                                                                                         "algorithmic_bytes_per_launch": shadow_bytes // world},
-                                           "whole frame, by wall clock": {"achieved": gbs(frame_bytes, elapsed / args.steps * 1e3),
-                                                                          "algorithmic_bytes": frame_bytes // world}},
-                         "note": "algorithmic bytes = 32/box test + 48/triangle test + 20/sphere test + 64/mesh entry + 20/ray hit record, "
-                                 "test counts exact from the counter build of the same kernels; duration = average of 10 launches running "
-                                 "alone (one frame in flight), HIP events on the launch stream; kernel_ms_in_flight holds the start-to-end "
-                                 "times inside the timed, overlapped region. "
-                                 "The BVH and triangle records (about 56 MB) stay L2 / Infinity-Cache resident, so HBM is the nominal bound only: "
-                                 "the figure counts the operands of every test, the caches serve most of them (frac can exceed 1), and "
-                                 "`traffic` is what the memory side really moved per launch (PMC)",
-                         "tests_per_ray": {"node": cnt["node"] / rays, "tri": cnt["tri"] / rays,
-                                           "closest_node": closest["node"] / max(cnt["primary"] + cnt["secondary"], 1),
-                                           "closest_tri": closest["tri"] / max(cnt["primary"] + cnt["secondary"], 1),
-                                           "shadow_node": sh["node"] / max(cnt["shadow"], 1), "shadow_tri": sh["tri"] / max(cnt["shadow"], 1)}},
-            # second bound of this path: fp32 vector work.  24 flops per box test, 60 per triangle test, 30 per sphere
-            # test, 31 per mesh entry, over the frame's wall-clock time; peak = CUs x 128 lanes x 2 (FMA) x clock
-            "valu": {"achieved": (24 * cnt["node"] + 60 * cnt["tri"] + 30 * cnt["sphere"] + 31 * cnt["mesh_entry"]) / world /
-                                 (elapsed / args.steps) / 1e12,
-                     "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     # measured counterpart: SIMD issue cycles taken by the frame's vector instructions (PMC pass of the same
-                     # workload) over the cycles available in this run's frame time; None without that pass or with N > 1
-                     "issue_fraction": pmc_valu_issue_fraction(wl_key, elapsed / args.steps * 1e3) if world == 1 else None,
-                     "note": "achieved = algorithmic flops of the tests (no selects, compares, address or stack work; no FMA "
-                             "contraction, so half the peak is out of reach by construction); issue_fraction says how busy the "
-                             "vector units really are"},
+                          "note": "launches running alone (one frame in flight), HIP events on the launch stream, measured after the timed region"},
+            "kernel_ms_in_flight": dict(zip(("frame", "trace_closest", "shade", "trace_shadow", "rest"), in_flight_stage)),
+            "fast_build": fast,
+            # The dominant kernel is the closest-hit trace of the primary rays.  What bounds it is fp32 vector work and the
+            # latency of its dependent loads, not HBM: its working set (BVH + triangle records) stays in L2 / Infinity Cache.
+            "roofline": {"bound": "valu_fp32", "kernel": "traceKernel<false,false> (closest hit, primary rays)",
+                         "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
+                         "algorithmic_flops_per_launch": closest_flops // world,
+                         "launch_ms": closest_ms,
+                         "traffic": prof.get("hbm_bytes_per_launch"),
+                         "traffic_source": prof_src if prof else None,
+                         "note": f"algorithmic flops = {NODE_FLOPS}/box test + {TRI_FLOPS}/triangle test + {SPHERE_FLOPS}/sphere test + "
+                                 f"{MESH_ENTRY_FLOPS}/mesh entry, test counts exact from the counter build of the same kernels in this run; "
+                                 "duration = average of 10 launches running alone (one frame in flight), HIP events on the launch stream; "
+                                 "peak = 256 CUs x 4 SIMDs x 32 lanes x 2 (FMA) x 2.4 GHz. The EXACT build may not fuse multiply-adds, so half the "
+                                 "peak is out of reach by construction; selects, compares, address and stack work are not counted",
+                         "tests_per_ray": {"closest_box": closest["node"] / max(traced, 1), "closest_triangle": closest["tri"] / max(traced, 1),
+                                           "shadow_box": sh["node"] / max(cnt["shadow"], 1), "shadow_triangle": sh["tri"] / max(cnt["shadow"], 1)},
+                         "hbm": {"bound": "hbm", "achieved": compulsory / (closest_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": compulsory / (closest_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "compulsory_bytes_per_launch": compulsory,
+                                 "note": "compulsory bytes = BVH nodes (32 B) + triangle records (48 B) of the scene, read once, + 20 B hit "
+                                         "record per ray; `traffic` above is what crossed the L2 -> fabric boundary per launch (PMC: 2 x "
+                                         "FETCH_SIZE + WRITE_SIZE, Infinity-Cache hits included) - L2 capacity misses of a 56 MB working "
+                                         "set in 8 x 4 MB L2s, not HBM reads"},
+                         "lane_use": wave_statistics(raw),
+                         "instructions": {"valu_per_launch": prof.get("valu_insts_per_launch"),
+                                          "valu_per_box_pair_or_triangle_phase": None,
+                                          "source": prof_src if prof else None},
+                         "other_kernels": {"traceKernel<true,false> (shadow, any hit)": {"achieved": tflops(shadow_flops, shadow_ms), "unit": "TFLOP/s",
+                                                                                         "algorithmic_flops_per_launch": shadow_flops // world,
+                                                                                         "launch_ms": shadow_ms},
+                                           "whole frame, by wall clock, frames in flight": {"achieved": tflops(closest_flops + shadow_flops, ms_per_step),
+                                                                                           "unit": "TFLOP/s"}}},
         }
         if not args.no_cpu and args.cpu_seconds > 0 and not multi:
             out["cpu_baseline"] = cpu_baseline(scene, args)

@@ -36,7 +36,39 @@ def tile_count(width, height, rank, world):
     return len(range(rank, tx * ty, world))
 
 
-def share_scene(blob, opts_bytes, camera_floats, rank, world, device):
+# A blob of this size or more travels as scatter + all-gather: rank 0 sends every rank a different 1/N slice and the
+# ranks then exchange slices, so that all of a GPU's xGMI links carry a share at once; a plain broadcast moves the
+# whole blob over one link after the other (ring) and is bound by a single link's rate.  Small blobs are latency-bound
+# either way and take the one-call broadcast.
+SCATTER_GATHER_BYTES = 64 << 20
+
+
+def share_blob(blob, nbytes, rank, world, device, scatter_gather=None):
+    """The scene blob (uint8 tensor on rank 0, None elsewhere) on every rank."""
+    if world == 1:
+        return blob
+    if scatter_gather is None:
+        scatter_gather = nbytes >= SCATTER_GATHER_BYTES
+    if not scatter_gather:
+        if rank != 0:
+            blob = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        dist.broadcast(blob, 0)
+        return blob
+    part = (nbytes + world - 1) // world
+    part = (part + 255) // 256 * 256  # slices keep the blob's 256-byte section alignment
+    out = torch.empty(part * world, dtype=torch.uint8, device=device)
+    slices = list(out.split(part))
+    if rank == 0:
+        out[:nbytes].copy_(blob)
+        dist.scatter(slices[0], [s.clone() if i == 0 else s for i, s in enumerate(slices)], src=0)
+    else:
+        dist.scatter(slices[rank], None, src=0)
+    mine = slices[rank].clone()
+    dist.all_gather(slices, mine)
+    return out[:nbytes]
+
+
+def share_scene(blob, opts_bytes, camera_floats, rank, world, device, scatter_gather=None):
     """Rank 0 passes the packed scene blob (uint8 tensor on `device`), the 48 raw bytes of DeviceOpts and the
     19 camera floats (origin + matrix); the other ranks pass None.  Returns (blob, opts_bytes, camera_floats) on every rank."""
     head = torch.zeros(1, dtype=torch.int64, device=device)
@@ -49,10 +81,7 @@ def share_scene(blob, opts_bytes, camera_floats, rank, world, device):
     if world > 1:
         dist.broadcast(head, 0)
         dist.broadcast(small, 0)
-    if rank != 0:
-        blob = torch.empty(int(head.item()), dtype=torch.uint8, device=device)
-    if world > 1:
-        dist.broadcast(blob, 0)
+    blob = share_blob(blob, int(head.item()), rank, world, device, scatter_gather)
     raw = small.cpu().numpy().tobytes()
     return blob, raw[:OPTS_BYTES], np.frombuffer(raw[OPTS_BYTES:], dtype=np.float32).copy()
 

@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 # the profiler initialises HIP before bench.py runs, so the queue count bench.py asks for is set here
 export GPU_MAX_HW_QUEUES=32
 # one frame in flight: the kernels run alone, as in the part of bench.py that measures the roofline
-ARGS="--steps 16 --warmup 4 --no-cpu --frames-in-flight 1 $*"
+ARGS="--steps 16 --warmup 4 --no-cpu --no-others --frames-in-flight 1 $*"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 bench.py $ARGS > "$OUT/trace.log" 2>&1 || { echo "trace pass failed"; tail -5 "$OUT/trace.log"; exit 1; }
 pass() {
   name=$1; shift
