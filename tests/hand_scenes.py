@@ -1,0 +1,231 @@
+"""Scene descriptions assembled by hand (ctypes structures of include/rt_capi.h), small enough that the value of a
+pixel can be derived on paper.  Used by the known-answer tests of the oracle (CPU) and of the HIP path (GPU)."""
+import ctypes as C
+
+import numpy as np
+
+from cudaraytracer_amd import _native as N
+
+DIFFUSE, GLASS, MIRROR = 0, 1, 2  # RT_MAT_*
+BG = (0.2, 0.7, 0.8)
+
+
+def texture(pixels, mode=1):
+    """pixels: [h][w] of (r, g, b) bytes -> (RtTexture, keep-alive buffer).  mode 1 = CLAMP, 0 = WRAP."""
+    a = np.asarray(pixels, dtype=np.uint8)
+    h, w = a.shape[:2]
+    rgba = np.concatenate([a, np.full((h, w, 1), 255, dtype=np.uint8)], axis=2).copy()
+    buf = (C.c_ubyte * rgba.size).from_buffer_copy(rgba.tobytes())
+    return N.RtTexture(w, h, C.cast(buf, C.POINTER(C.c_ubyte)), mode), buf
+
+
+WHITE = [[(255, 255, 255)]]
+BLACK = [[(0, 0, 0)]]
+FLAT_NORMAL = [[(128, 128, 255)]]
+
+
+class Mesh:
+    """One mesh: triangles as lists of three vertices {pos, uv, normal}; tangent and bitangent are zero, so the shading
+    normal is the interpolated vertex normal whatever the normal map holds.  `nodes`: None = all triangles in one leaf,
+    else a list of (bbmin, bbmax, offset, primCnt, axis) in the reference's depth-first order."""
+
+    def __init__(self, triangles, material=DIFFUSE, ior=1.3, ks=0.0, spec_exp=25.0, diffuse=WHITE, specular=BLACK, normals=FLAT_NORMAL,
+                 nodes=None, mode=1):
+        self.triangles, self.material, self.ior, self.ks, self.spec_exp = triangles, material, ior, ks, spec_exp
+        self.maps = (diffuse, normals, specular)
+        self.nodes, self.mode = nodes, mode
+
+
+def tri(p0, p1, p2, uv=((0, 0), (1, 0), (0, 1)), normal=(0, 0, -1)):
+    return [{"pos": p, "uv": t, "normal": normal} for p, t in zip((p0, p1, p2), uv)]
+
+
+class Scene:
+    def __init__(self, w, h, meshes=(), spheres=(), lights=(), max_depth=0, bias=1e-4, gamma=0, camera=None, origin=(0, 0, 0)):
+        self.keep = []
+        self.width, self.height = w, h
+        nm, ns = len(meshes), len(spheres)
+        self.meshes = (N.RtMesh * max(nm, 1))()
+        self.shapes = (N.RtShape * (nm + ns))()
+        lo = np.full(3, np.finfo(np.float32).max, dtype=np.float32)
+        hi = -lo
+        for mi, m in enumerate(meshes):
+            nt = len(m.triangles)
+            verts = (N.RtVertex * (3 * nt))()
+            tris = (N.RtTriangle * nt)()
+            pos = []
+            for t, corners in enumerate(m.triangles):
+                for k, c in enumerate(corners):
+                    v = verts[3 * t + k]
+                    v.position[:] = c["pos"]
+                    v.texCoord[:] = c["uv"]
+                    v.normal[:] = c["normal"]
+                    tris[t].i[k] = 3 * t + k
+                    pos.append(c["pos"])
+            pos = np.asarray(pos, dtype=np.float32)
+            b0, b1 = pos.min(0), pos.max(0)
+            spec = m.nodes if m.nodes is not None else [(b0.tolist(), b1.tolist(), 0, nt, 0)]
+            nodes = (N.RtLinearNode * len(spec))()
+            for i, (mn, mx, off, cnt, axis) in enumerate(spec):
+                nodes[i].bbmin[:], nodes[i].bbmax[:] = mn, mx
+                nodes[i].offset, nodes[i].primCnt, nodes[i].axis = off, cnt, axis
+            dm = self.meshes[mi]
+            dm.triangleCnt, dm.triangles, dm.vertexCnt, dm.vertices = nt, tris, 3 * nt, verts
+            dm.nodeCnt, dm.nodes = len(spec), nodes
+            for name, px in zip(("diffuse", "normals", "specular"), m.maps):
+                tex, buf = texture(px, m.mode)
+                setattr(dm, name, tex)
+                self.keep.append(buf)
+            dm.transformInverse[:] = np.eye(4, dtype=np.float32).ravel().tolist()
+            s = self.shapes[mi]
+            s.kind, s.meshIdx, s.tag = 1, mi, mi
+            s.material.materialType, s.material.ior, s.material.Kd, s.material.Ks, s.material.specularExponent = m.material, m.ior, 0.8, m.ks, m.spec_exp
+            s.material.diffuseColor[:] = [0.2, 0.2, 0.2]
+            s.bbmin[:], s.bbmax[:] = b0.tolist(), b1.tolist()
+            lo, hi = np.minimum(lo, b0), np.maximum(hi, b1)
+            self.keep += [verts, tris, nodes]
+        for si, (c, r, mat, ior, color) in enumerate(spheres):
+            s = self.shapes[nm + si]
+            s.kind, s.meshIdx, s.tag = 0, -1, nm + si
+            s.center[:] = c
+            s.radius, s.radius2 = r, float(np.float32(r) * np.float32(r))
+            s.material.materialType, s.material.ior, s.material.Kd, s.material.Ks, s.material.specularExponent = mat, ior, 0.8, 0.0, 25.0
+            s.material.diffuseColor[:] = color
+            b0, b1 = np.float32(c) - np.float32(r), np.float32(c) + np.float32(r)
+            s.bbmin[:], s.bbmax[:] = b0.tolist(), b1.tolist()
+            lo, hi = np.minimum(lo, b0), np.maximum(hi, b1)
+        self.nodes = (N.RtLinearNode * 1)()
+        self.nodes[0].bbmin[:], self.nodes[0].bbmax[:] = lo.tolist(), hi.tolist()
+        self.nodes[0].offset, self.nodes[0].primCnt = 0, nm + ns
+        self.lights = (N.RtLight * max(len(lights), 1))()
+        for i, (p, intensity, power) in enumerate(lights):
+            self.lights[i].position[:] = p
+            self.lights[i].intensity[:] = intensity
+            self.lights[i].power = power
+        self.desc = N.RtSceneDesc(self.lights if lights else None, len(lights), self.shapes, nm + ns, self.meshes if nm else None, nm,
+                                  self.nodes, 1)
+        self.opts = N.RtDeviceOpts()
+        o = self.opts
+        o.imageAspectRatio, o.scale = w / h, 1.0
+        o.width, o.height = w, h
+        o.backgroundColor[:] = BG
+        o.shadowBias, o.blockSize, o.maxDepth, o.samples = bias, 4, max_depth, 1
+        o.gammaCorrection, o.useSceneBvh, o.useMeshBvhs = gamma, 1, 1
+        self.camera = N.RtCamera()
+        self.camera.orig[:] = origin
+        self.camera.camera[:] = (np.eye(4, dtype=np.float32) if camera is None else np.asarray(camera, dtype=np.float32)).ravel().tolist()
+
+    def render_oracle(self, oracle):
+        rgba, keys, _ = oracle.render(C.pointer(self.desc), C.pointer(self.opts), C.pointer(self.camera), self.width, self.height, threads=1,
+                                      shadow_any_hit=True)
+        return rgba, keys
+
+    def render_gpu(self, ctx):
+        w, h = self.width, self.height
+        dscene = ctx.upload(C.pointer(self.desc))
+        surf, pitch = ctx.surface(w, h)
+        keys = ctx.alloc(w * h * 16)
+        try:
+            ctx.render(dscene, self.opts, C.pointer(self.camera), surf, pitch, keys)
+            ctx.sync()
+            return ctx.download_surface(surf, pitch, w, h), ctx.download(keys, (h, w, 4), np.int32)
+        finally:
+            ctx.free(surf)
+            ctx.free(keys)
+            ctx.free_scene(dscene)
+
+
+# ---- the probes: (scene, what the centre pixel / the key plane must be), derived by hand -----------------------------
+# A 1x1 frame has ONE ray: ndc = 2 * 0.5 - 1 = 0, direction (0, 0, 1) exactly.  Gamma is off, so a pixel is the sum
+# the reference's diffuseAndGlossy forms.  With the light AT the camera (origin), a surface facing the camera at
+# distance t, specular map black:  pixel = intensity * power / t * lambert * diffuse texel, lambert = 1.
+
+FRONT = ((-3, -3, 5), (-3, 6, 5), (6, -3, 5))  # counter-clockwise seen from the origin: det = e1 . (d x e2) = 81 > 0, centroid (0, 0, 5)
+BACK = (FRONT[0], FRONT[2], FRONT[1])
+LIGHT_AT_CAMERA = [((0, 0, 0), (1, 1, 1), 5.0)]
+
+
+def probes():
+    """name -> (Scene, expected centre pixel rgb or None, expected centre hit key or None)."""
+    P = {}
+    # Moller-Trumbore through the centroid: t = 5, so pixel = 1 * 5 / 5 * 1 * white = 1 (cudaTracer/Mesh.cuh:182-212)
+    P["triangle_centroid"] = (Scene(1, 1, [Mesh([tri(*FRONT)])], lights=LIGHT_AT_CAMERA), (1.0, 1.0, 1.0), (0, 0, 1, 2))
+    # the same triangle wound the other way is culled (det < 0): the ray leaves the scene
+    P["triangle_backface"] = (Scene(1, 1, [Mesh([tri(*BACK)])], lights=LIGHT_AT_CAMERA), BG, (-1, -1, -1, -1))
+    # sphere of radius 1 at z = 5 from outside: nearest root t = 4, normal (0, 0, -1): pixel = 5 / 4 * colour (Sphere.cuh:41-54)
+    P["sphere_outside"] = (Scene(1, 1, spheres=[((0, 0, 5), 1.0, DIFFUSE, 1.3, (0.4, 0.2, 0.1))], lights=LIGHT_AT_CAMERA),
+                           (0.5, 0.25, 0.125), (0, -1, -1, -1))
+    # from the centre of the sphere: the negative root is dropped, t = 1 at (0, 0, 6); the normal points away from every
+    # light that the surface can see, so the pixel is black - but it is a hit, not the background
+    P["sphere_inside"] = (Scene(1, 1, spheres=[((0, 0, 5), 1.0, DIFFUSE, 1.3, (0.4, 0.2, 0.1))], lights=LIGHT_AT_CAMERA, origin=(0, 0, 5)),
+                          (0.0, 0.0, 0.0), (0, -1, -1, -1))
+    # sphere behind the ray origin: both roots negative
+    P["sphere_behind"] = (Scene(1, 1, spheres=[((0, 0, 5), 1.0, DIFFUSE, 1.3, (0.4, 0.2, 0.1))], lights=LIGHT_AT_CAMERA, origin=(0, 0, 7)),
+                          BG, (-1, -1, -1, -1))
+    # mirror at normal incidence: the reflected ray leaves the scene, pixel = background * ((n - 1) / (n + 1))^2 = bg * 0.04
+    # for n = 1.5 (cudaTracer/tracer.cu:67-89, 134-142)
+    P["fresnel_normal_incidence"] = (Scene(1, 1, [Mesh([tri(*FRONT)], material=MIRROR, ior=1.5)], lights=LIGHT_AT_CAMERA, max_depth=1),
+                                     tuple(0.04 * c for c in BG), (0, 0, 1, 2))
+    # the same mirror with the shading normal along the ray (cos > 0: "leaving the denser medium") and the ray turned
+    # 60 degrees about y: sin_t = 1.5 * sin 60 > 1, total internal reflection, kr = 1: pixel = background
+    c60, s60 = 0.5, float(np.sqrt(0.75))
+    roty = [[c60, 0, -s60, 0], [0, 1, 0, 0], [s60, 0, c60, 0], [0, 0, 0, 1]]  # row-vector convention: (0, 0, 1) -> (s60, 0, c60)
+    big = ((-30, -30, 5), (-30, 60, 5), (60, -30, 5))
+    P["fresnel_total_internal_reflection"] = (Scene(1, 1, [Mesh([tri(*big, normal=(0, 0, 1))], material=MIRROR, ior=1.5)], lights=LIGHT_AT_CAMERA,
+                                                    max_depth=1, camera=roty), BG, (0, 0, 1, 2))
+    # glass at normal incidence: the refracted ray keeps its direction (tracer.cu:102-115) and reaches a small lit sphere
+    # behind the pane.  So does the "reflected" ray: the reference reflects the NORMAL about the view direction there
+    # (tracer.cu:119, operands swapped), which at normal incidence points forward too.  Both children return the sphere's
+    # radiance 5 / 2.5 * colour (light at z = 7, sphere front at z = 9.5): pixel = sphere * 0.04 + sphere * 0.96
+    P["refract_normal_incidence"] = (Scene(1, 1, [Mesh([tri(*FRONT)], material=GLASS, ior=1.5)],
+                                           spheres=[((0, 0, 10), 0.5, DIFFUSE, 1.3, (0.1, 0.2, 0.3))],
+                                           lights=[((0, 0, 7), (1, 1, 1), 5.0)], max_depth=1),
+                                     (0.2, 0.4, 0.6), (0, 0, 1, 2))
+    # shadow rays accept a hit at t == tMax (Mesh.cuh:203-205): with bias 0 the shadow ray starts on the surface at
+    # (0, 0, 5), the light is exactly 3 away at (0, 0, 2), and a triangle facing the surface lies in the plane z = 2:
+    # every product of its Moller-Trumbore test is exact, t = 48 / 16 = 3 == tMax: in shadow, pixel black.  (That
+    # triangle is back-facing for the primary ray, which therefore passes through it.)  Moved to z = 1.75 the triangle
+    # is behind the light (t = 3.25 > tMax): lit, pixel = 5 / 3.
+    # (A second, far-off triangle at z + 0.5 makes the occluder mesh's box start before the light: a box that begins
+    # exactly at the reach fails the box test's strict "entry < tMax", cudaTracer/BoundingBox.cuh:138 - see the third probe.)
+    occl = lambda z: [tri((-1, -1, z), (3, -1, z), (-1, 3, z)),  # noqa: E731  det = 16 > 0 for direction (0, 0, -1)
+                      tri((10, 10, z + 0.5), (11, 10, z + 0.5), (10, 11, z + 0.5))]
+    light = [((0, 0, 2), (1, 1, 1), 5.0)]
+    P["shadow_hit_at_reach_is_accepted"] = (Scene(1, 1, [Mesh([tri(*FRONT)]), Mesh(occl(2.0))], lights=light, bias=0.0), (0.0, 0.0, 0.0), (0, 0, 1, 2))
+    P["shadow_occluder_beyond_the_light"] = (Scene(1, 1, [Mesh([tri(*FRONT)]), Mesh(occl(1.75))], lights=light, bias=0.0),
+                                             (5.0 / 3, 5.0 / 3, 5.0 / 3), (0, 0, 1, 2))
+    # the same occluder alone in its mesh: the mesh's root box is flat at z = 2, its entry distance 3 is not < tMax = 3,
+    # the box is skipped and the triangle never tested: lit
+    P["shadow_box_starting_at_the_reach_is_skipped"] = (Scene(1, 1, [Mesh([tri(*FRONT)]), Mesh(occl(2.0)[:1])], lights=light, bias=0.0),
+                                                        (5.0 / 3, 5.0 / 3, 5.0 / 3), (0, 0, 1, 2))
+    # two identical triangles in one leaf: equal t, the later one replaces the earlier (t <= tMax, Mesh.cuh:203)
+    P["equal_t_later_triangle_wins"] = (Scene(1, 1, [Mesh([tri(*FRONT), tri(*FRONT)])], lights=LIGHT_AT_CAMERA), (1.0, 1.0, 1.0), (0, 3, 4, 5))
+    return P
+
+
+def bilinear_scene(u, v, mode=1):
+    """A camera-facing triangle whose three corners carry the SAME texture coordinate, so st = (u, v) at the hit; 2x2
+    diffuse map; light at the camera, t = 5, power 5: the pixel is the filtered texel (cudaTracer/Texture.cuh:33-69)."""
+    px = [[(255, 0, 0), (0, 255, 0)], [(0, 0, 255), (255, 255, 255)]]
+    return Scene(1, 1, [Mesh([tri(*FRONT, uv=((u, v),) * 3)], diffuse=px, mode=mode)], lights=LIGHT_AT_CAMERA)
+
+
+# (u, v, mode) -> expected rgb: texel centres sit at (x + 0.5) / 2
+BILINEAR = [
+    ((0.25, 0.25, 1), (1, 0, 0)), ((0.75, 0.25, 1), (0, 1, 0)), ((0.25, 0.75, 1), (0, 0, 1)), ((0.75, 0.75, 1), (1, 1, 1)),  # centres
+    ((0.5, 0.25, 1), (0.5, 0.5, 0)), ((0.25, 0.5, 1), (0.5, 0, 0.5)), ((0.5, 0.5, 1), (0.5, 0.5, 0.5)),  # midway: the mean
+    ((0.0, 0.0, 1), (1, 0, 0)), ((1.0, 1.0, 1), (1, 1, 1)), ((1.0, 0.0, 1), (0, 1, 0)),  # CLAMP repeats the edge texel
+    ((0.0, 0.25, 0), (0.5, 0.5, 0)),  # WRAP: the left neighbour of texel 0 is texel 1
+]
+
+
+def flip_scene(w=8, h=8):
+    """Two identical camera-facing triangles in two leaves under an interior node split along x.  Both leaves' boxes
+    (z from 4 to 6, so that they are entered before the hit at z = 5) are hit by every ray, both triangles at the same
+    t: the triangle visited LAST wins.  cudaTracer/Mesh.cuh:155-161 visits the first child first for rays going towards
+    +x and the second child first for rays going towards -x, so pixels right of the centre report the second triangle
+    (vertices 3, 4, 5), pixels left of it the first (0, 1, 2)."""
+    wide = ((-30, -30, 5), (-30, 60, 5), (60, -30, 5))
+    lo, hi = [-30, -30, 4], [60, 60, 6]
+    nodes = [(lo, hi, 2, 0, 0), (lo, hi, 0, 1, 0), (lo, hi, 1, 1, 0)]
+    return Scene(w, h, [Mesh([tri(*wide), tri(*wide)], nodes=nodes)], lights=LIGHT_AT_CAMERA)

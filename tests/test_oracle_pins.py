@@ -1,8 +1,9 @@
 """Pins the CPU oracle (and the host API classes) to the reference's own unit-test
 assertions: cudaTracer/VectorTest.cpp, Tests.cpp, BoundingBoxTest.cpp, BvhTest.cpp.
-Those are the only known answers the reference holds for this path; traversal,
-triangle / sphere tests, texture filtering and shading have none (parity unpinned,
-covered by restatement + cross-checks only)."""
+Those are the only known answers the reference itself holds for this path; for
+traversal order, triangle / sphere tests, Fresnel / refraction, texture filtering and
+the tie rule, tests/test_known_answers.py adds answers derived by hand from the
+reference's formulas."""
 import ctypes as C
 
 import numpy as np
