@@ -325,6 +325,10 @@ class Context:
         """1 = frames run in order on the context's stream; 2..8 = consecutive frames overlap on internal streams."""
         self._check(self.lib.rt_set_frames_in_flight(self.ctx, frames), "rt_set_frames_in_flight")
 
+    def set_accumulation(self, dev_sum, pitch=0, samples_so_far=0):
+        """Running-sum surface for progressive accumulation over frames (None ends it)."""
+        self._check(self.lib.rt_set_accumulation(self.ctx, dev_sum, pitch, samples_so_far), "rt_set_accumulation")
+
     def set_arithmetic(self, fast):
         """False = exact (bit-identical to the reference's formulas), True = the fast build of the kernels."""
         self._check(self.lib.rt_set_arithmetic(self.ctx, 1 if fast else 0), "rt_set_arithmetic")

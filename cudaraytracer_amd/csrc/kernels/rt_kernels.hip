@@ -239,10 +239,11 @@ __device__ __forceinline__ V3 primaryDir(const FrameParams& P, int x, int y, int
     const float ndcX = (2.0f * ((float)x + 0.5f) * widthScale - 1.0f) * P.opts.imageAspectRatio * P.opts.scale;
     const float ndcY = (1.0f - 2.0f * ((float)y + 0.5f) * heightScale) * P.opts.scale;
     float xJitter = 0.0f, yJitter = 0.0f;
-    if (P.opts.samples > 1) {
+    if (P.opts.samples > 1 || P.accum) {
+        // accumulating over frames, this call's samples continue the numbering of the earlier calls
         const uint32_t pixel = (uint32_t)y * (uint32_t)P.opts.width + (uint32_t)x;
-        xJitter = rt_sample_jitter(P.sampleSeed, pixel, (uint32_t)sample, 0u);
-        yJitter = rt_sample_jitter(P.sampleSeed, pixel, (uint32_t)sample, 1u);
+        xJitter = rt_sample_jitter(P.sampleSeed, pixel, P.sampleBase + (uint32_t)sample, 0u);
+        yJitter = rt_sample_jitter(P.sampleSeed, pixel, P.sampleBase + (uint32_t)sample, 1u);
     }
     V3 dir = normalized(mk(ndcX + xJitter * widthScale, ndcY + yJitter * heightScale, 1.0f));
     const float* C = P.camera;
@@ -955,7 +956,7 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams P, const in
             } else if (shapeSlot < 0) {
                 P.color[node] = make_float4(bg.x, bg.y, bg.z, 0.0f);
                 P.kind[node] = NODE_DONE;
-                if (level == 0 && P.hitKeys && slotSample(P, node) == 0) {
+                if (level == 0 && P.hitKeys && P.sampleBase + (uint32_t)slotSample(P, node) == 0u) {
                     int x, y;
                     slotPixel(P, node, x, y);
                     *reinterpret_cast<int4*>(P.hitKeys + ((size_t)y * P.opts.width + x) * 4) = make_int4(-1, -1, -1, -1);
@@ -980,7 +981,7 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams P, const in
                     key.w = rec->idx[2];
                     if (COUNT) cMesh++;
                 }
-                if (level == 0 && P.hitKeys && slotSample(P, node) == 0) {
+                if (level == 0 && P.hitKeys && P.sampleBase + (uint32_t)slotSample(P, node) == 0u) {
                     int x, y;
                     slotPixel(P, node, x, y);
                     *reinterpret_cast<int4*>(P.hitKeys + ((size_t)y * P.opts.width + x) * 4) = key;
@@ -1149,9 +1150,14 @@ __global__ void __launch_bounds__(256) finalizeKernel(const FrameParams P) {
         int x, y;
         if (!slotPixel(P, (int)first, x, y)) continue;
         // cudaTracer/Main.cu:66-82: the samples are added up in order, starting from zero, then divided
+        // Accumulating over frames (rt_set_accumulation), the sum continues where the previous call left it, sample by
+        // sample in the same order, so that N calls of one sample add up exactly like one call of N samples.
         V3 col = mk(0.0f, 0.0f, 0.0f);
+        float4* const sum = P.accum ? reinterpret_cast<float4*>(P.accum + (size_t)y * P.accumPitch + (size_t)x * 16) : nullptr;
+        if (sum && P.sampleBase != 0u) col = mk(*sum);
         for (int i = 0; i < S; ++i) col = add(col, mk(P.color[first + ((unsigned)i << 6)]));
-        const float samples = (float)S;
+        const float samples = (float)(P.sampleBase + (uint32_t)S);
+        if (sum) *sum = make_float4(col.x, col.y, col.z, samples);
         col = mk(col.x / samples, col.y / samples, col.z / samples);
         float4 out;
         if (P.opts.gammaCorrection) {

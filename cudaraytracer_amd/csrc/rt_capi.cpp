@@ -85,6 +85,10 @@ struct rt_ctx {
     int ldsStack = RT_LDS_STACK_DEFAULT;  // traversal stack entries kept in LDS (older ones move to global memory)
     int maxWavesPerCu = 0;                // 0 = as many as are resident
     uint32_t sampleSeed = 1234;
+    // rt_set_accumulation: running sum surface and the samples it holds
+    unsigned char* accum = nullptr;
+    size_t accumPitch = 0;
+    uint32_t accumSamples = 0;
     BuildParams bvhBuild;  // for meshes that arrive without BVH nodes
     int tileOrderMode = RT_TILE_ORDER_CENTER_OUT;
     // tile orders already on the device, by (tile grid, shard, frame size); a table is never changed once made
@@ -706,6 +710,16 @@ int rt_set_sample_seed(rt_ctx* ctx, uint32_t seed) {
     return RT_OK;
 }
 
+int rt_set_accumulation(rt_ctx* ctx, void* devSum, size_t sumPitch, uint32_t samplesSoFar) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (devSum && (sumPitch % 16 != 0 || (reinterpret_cast<uintptr_t>(devSum) & 15))) return fail(ctx, RT_ERR_INVALID, "accumulation surface must be 16-byte aligned with a pitch that is a multiple of 16");
+    if (samplesSoFar > (1u << 24)) return fail(ctx, RT_ERR_LIMIT, "accumulation holds at most 2^24 samples per pixel");
+    ctx->accum = static_cast<unsigned char*>(devSum);
+    ctx->accumPitch = devSum ? sumPitch : 0;
+    ctx->accumSamples = devSum ? samplesSoFar : 0;
+    return RT_OK;
+}
+
 int rt_set_tile_order(rt_ctx* ctx, int mode) {
     if (!ctx) return RT_ERR_INVALID;
     if (mode != RT_TILE_ORDER_ROW_MAJOR && mode != RT_TILE_ORDER_CENTER_OUT) return fail(ctx, RT_ERR_INVALID, "unknown tile order %d", mode);
@@ -1061,6 +1075,15 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
     p.tileCnt = (int)myTiles;
     p.slots = p.tileCnt * RT_TILE * RT_TILE * opts->samples;
     p.sampleSeed = ctx->sampleSeed;
+    if (ctx->accum) {
+        if (ctx->framesInFlight > 1) return fail(ctx, RT_ERR_INVALID, "accumulation over frames needs frames in order (rt_set_frames_in_flight(1)): every frame continues the previous one's sums");
+        if (ctx->accumPitch < (size_t)opts->width * 16) return fail(ctx, RT_ERR_INVALID, "accumulation surface pitch holds fewer than %d float4 pixels", opts->width);
+        if ((unsigned long long)ctx->accumSamples + (unsigned)opts->samples > (1u << 24))
+            return fail(ctx, RT_ERR_LIMIT, "accumulation holds at most 2^24 samples per pixel (the count is kept in fp32)");
+        p.accum = ctx->accum;
+        p.accumPitch = ctx->accumPitch;
+        p.sampleBase = ctx->accumSamples;
+    }
     p.nodeCap = p.slots * budget;
 
     if (noAlloc) {
@@ -1103,6 +1126,7 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
         hipError_t e = (hipError_t)renderKernels(&p, secondary, p.counters ? 1 : 0, ctx->cuCount, ctx->stream, nullptr);
         if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
         ctx->scratchMayOverflow = ctx->scratchMayOverflow || (secondary && opts->maxDepth > 0);
+        if (ctx->accum) ctx->accumSamples += (uint32_t)opts->samples;
         return RT_OK;
     }
 
@@ -1210,6 +1234,7 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
     sl.lastStream = exec;
     ctx->frameCounter++;
     ctx->launchesUsed++;
+    if (ctx->accum) ctx->accumSamples += (uint32_t)opts->samples;
     return RT_OK;
 }
 

@@ -174,6 +174,9 @@ struct FrameParams {
     const int32_t* tileOrder;                // optional [tileCnt]: frame tile of local tile k (overrides the arithmetic rule)
     int32_t slots;                           // tileCnt * samples * 64 level-0 nodes
     uint32_t sampleSeed;
+    uint32_t sampleBase;                     // samples of earlier calls when accumulating over frames (else 0)
+    unsigned char* accum;                    // optional running sum surface: float4 {sum r, g, b, samples} per pixel
+    uint64_t accumPitch;
     int32_t nodeCap;                         // capacity of the per-node arrays
     int32_t stackEntries;                    // per-lane traversal stack entries needed (8 bytes each)
     int32_t stackLds;                        // size of the LDS ring holding the top of the stack (a power of two)

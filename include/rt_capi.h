@@ -358,6 +358,20 @@ int rt_set_device_bvh(rt_ctx* ctx, int threshold, int tightBounds);
 int rt_set_sample_seed(rt_ctx* ctx, uint32_t seed);
 #define RT_MAX_SAMPLES 64
 
+/* Progressive accumulation over frames, on the device: the successor of the reference's per-launch sample loop
+ * (cudaTracer/Main.cu:66-98).  `devSum` is a float4 surface of the frame's size in device memory (row stride
+ * `sumPitch` bytes) that holds, per pixel, {sum of r, g, b over all samples so far, number of samples}.  While it is
+ * set, every rt_render / rt_render_noalloc call
+ *   - numbers its opts->samples samples behind the `samplesSoFar` of the earlier calls (sample k of a pixel always
+ *     gets the jitter rt_sample_jitter(seed, pixel, k, axis), also when a call renders a single sample),
+ *   - adds them to the sums one after the other, in order, and
+ *   - writes to the frame surface the average over ALL samples so far, gamma-corrected as Main.cu:80-98 does.
+ * N calls of one sample therefore give, bit for bit, the frame of one call with N samples (and any other split of
+ * N).  `samplesSoFar` = 0 starts a new accumulation (the surface's old contents are ignored); the library counts on
+ * from there.  devSum = NULL ends it.  Frames must run in order (rt_set_frames_in_flight(1)); with tile shards every
+ * call accumulates its own tiles.  At most 2^24 samples per pixel. */
+int rt_set_accumulation(rt_ctx* ctx, void* devSum, size_t sumPitch, uint32_t samplesSoFar);
+
 /* Order in which a call's 8x8 tiles enter the trace kernels' work queue.  Which tiles
  * are rendered and every pixel value are the same either way.  CENTER_OUT (default)
  * starts with the tiles nearest the image centre, where rays usually take longest,
