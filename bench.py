@@ -213,6 +213,20 @@ def other_workload(ctx, torch, dev, label, scene_args, scene_kwargs, nf):
             "scene_build_s": round(build_s, 2), "upload_s": round(upload_s, 2)}
 
 
+class mg_single:
+    """The swap chain without a gather (one GPU): same step / drain calls as cudaraytracer_amd.multi.FramePipeline."""
+
+    def __init__(self, surfaces, render):
+        self.surfaces, self.render, self.issued = surfaces, render, 0
+
+    def step(self):
+        self.render(self.surfaces[self.issued % len(self.surfaces)])
+        self.issued += 1
+
+    def drain(self):
+        self.issued = 0
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -289,25 +303,14 @@ def main():
     surface = surfaces[0]
     pitch = w * 16
     gatherer = mg.TileGather(w, h, rank, world, comm_dev) if multi else None
-    issued = [0]
-
-    def collect(frames_ago):
-        """Orders torch's stream behind the frame issued `frames_ago` calls ago and gathers its tiles to rank 0
-        (where the frame then sits as 8x8-pixel tiles, rank by rank; TileGather.assembled() lays it out as rows)."""
-        ctx.stream_wait_frame(stream.cuda_stream, frames_ago)
-        gatherer.gather(surfaces[(issued[0] - 1 - frames_ago) % nf].to(comm_dev), assemble=False)
-
-    def step():
-        ctx.render(dscene, opts, camera_ref, surfaces[issued[0] % nf].data_ptr(), pitch, None, None, rank, world)
-        issued[0] += 1
-        if multi and issued[0] >= nf:
-            collect(nf - 1)  # the oldest frame in flight; the newer ones keep running meanwhile
-
-    def drain():
-        if multi:
-            for ago in range(min(nf - 1, issued[0]) - 1, -1, -1):
-                collect(ago)
-        issued[0] = 0
+    if multi:
+        # frame i renders into surface i % F; the oldest frame in flight is gathered to rank 0 (where it then sits as
+        # 8x8-pixel tiles, rank by rank; TileGather.assembled() lays it out as rows) while the newer ones keep rendering
+        pipe = mg.FramePipeline(surfaces, lambda s, i: ctx.render(dscene, opts, camera_ref, s.data_ptr(), pitch, None, None, rank, world),
+                                lambda ago: ctx.stream_wait_frame(stream.cuda_stream, ago), gatherer, (lambda s: s.to(comm_dev)))
+    else:
+        pipe = mg_single(surfaces, lambda s: ctx.render(dscene, opts, camera_ref, s.data_ptr(), pitch))
+    step, drain = pipe.step, pipe.drain
 
     # ---- exact ray / test counts of the frame (untimed counter build) ----
     cnt_buf = counters_of(ctx, dscene, opts, camera_ref, surface.data_ptr(), pitch, rank, world)

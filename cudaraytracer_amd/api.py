@@ -329,6 +329,17 @@ class Context:
         """Running-sum surface for progressive accumulation over frames (None ends it)."""
         self._check(self.lib.rt_set_accumulation(self.ctx, dev_sum, pitch, samples_so_far), "rt_set_accumulation")
 
+    def set_tile_list(self, tiles):
+        """The tiles (frame tile indices, in queue order) of the following render calls; None returns to tileFirst / tileStride."""
+        if tiles is None or len(tiles) == 0:
+            self._check(self.lib.rt_set_tile_list(self.ctx, None, 0), "rt_set_tile_list")
+            return
+        a = np.ascontiguousarray(np.asarray(tiles, dtype=np.int32))
+        self._check(self.lib.rt_set_tile_list(self.ctx, a.ctypes.data, int(a.size)), "rt_set_tile_list")
+
+    def set_tile_cost_buffer(self, dev_ptr):
+        self._check(self.lib.rt_set_tile_cost_buffer(self.ctx, dev_ptr), "rt_set_tile_cost_buffer")
+
     def set_arithmetic(self, fast):
         """False = exact (bit-identical to the reference's formulas), True = the fast build of the kernels."""
         self._check(self.lib.rt_set_arithmetic(self.ctx, 1 if fast else 0), "rt_set_arithmetic")

@@ -403,6 +403,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     const float kInf = __builtin_huge_valf();
 
     unsigned cNode = 0, cTri = 0, cSphere = 0, cMesh = 0, cRays = 0, cPrimary = 0;
+    unsigned rayTests = 0;  // cNode + cTri when the lane's current ray started (COUNT: per-tile cost)
     // wave-level statistics (meaningful in lane 0): iterations, node steps and their lanes, triangle phases and their
     // rays, lanes holding a ray
     unsigned long long wSteps = 0, wNodeLanes = 0, wTriLanes = 0, wBusyLanes = 0, wNodeSteps = 0, wTriSteps = 0;
@@ -511,7 +512,10 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     }
                 }
                 if (valid) {
-                    if (COUNT) cRays++;
+                    if (COUNT) {
+                        cRays++;
+                        rayTests = cNode + cTri;
+                    }
                     inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                     hShape = -1;
                     hTri = -1;
@@ -760,6 +764,16 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
 
         // ---- finished lanes publish their result and give up their ray -----
         if (item >= 0 && cur == CUR_DONE) {
+            if (COUNT && P.tileCost) {
+                // box + triangle tests of this ray, booked on the frame tile of its pixel (primary rays and the shadow
+                // rays of primary hits; deeper rays are not attributed)
+                const int node = ANY ? P.ctxNode[(unsigned)item / (unsigned)P.lightCnt] : item;
+                if (node < P.slots) {
+                    const int local = P.opts.samples == 1 ? node >> 6 : (node >> 6) / P.opts.samples;
+                    const int tile = P.tileOrder ? P.tileOrder[local] : P.tileFirst + local * P.tileStride;
+                    atomicAdd(P.tileCost + tile, cNode + cTri - rayTests);
+                }
+            }
             if (ANY) {
                 P.vis[item] = hShape != -1 ? 0 : 1;
             } else {

@@ -85,6 +85,10 @@ struct rt_ctx {
     int ldsStack = RT_LDS_STACK_DEFAULT;  // traversal stack entries kept in LDS (older ones move to global memory)
     int maxWavesPerCu = 0;                // 0 = as many as are resident
     uint32_t sampleSeed = 1234;
+    // rt_set_tile_list: the tiles of the following calls, on the device, in the caller's order
+    int32_t* tileList = nullptr;
+    int tileListCnt = 0, tileListMax = -1;
+    uint32_t* tileCost = nullptr;  // rt_set_tile_cost_buffer
     // rt_set_accumulation: running sum surface and the samples it holds
     unsigned char* accum = nullptr;
     size_t accumPitch = 0;
@@ -628,6 +632,7 @@ void rt_destroy(rt_ctx* ctx) {
     }
     for (auto& t : ctx->tileOrders)
         if (t.dev) hipFree(t.dev);
+    if (ctx->tileList) hipFree(ctx->tileList);
     for (int k = 0; k < 2; ++k) {
         if (ctx->staging[k]) hipHostFree(ctx->staging[k]);
         if (ctx->stagingDone[k]) hipEventDestroy(ctx->stagingDone[k]);
@@ -707,6 +712,39 @@ int rt_set_trace_waves(rt_ctx* ctx, int wavesPerCu) {
 int rt_set_sample_seed(rt_ctx* ctx, uint32_t seed) {
     if (!ctx) return RT_ERR_INVALID;
     ctx->sampleSeed = seed;
+    return RT_OK;
+}
+
+int rt_set_tile_list(rt_ctx* ctx, const int32_t* tiles, int count) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (count < 0 || (count > 0 && !tiles)) return fail(ctx, RT_ERR_INVALID, "bad tile list");
+    if (int r = bind(ctx)) return r;
+    if (int r = syncFrames(ctx)) return r;  // frames in flight may still read the old list
+    if (ctx->tileList) hipFree(ctx->tileList);
+    ctx->tileList = nullptr;
+    ctx->tileListCnt = 0;
+    ctx->tileListMax = -1;
+    if (count == 0) return RT_OK;
+    std::vector<int32_t> sorted(tiles, tiles + count);
+    std::sort(sorted.begin(), sorted.end());
+    if (sorted.front() < 0) return fail(ctx, RT_ERR_INVALID, "negative tile index in the tile list");
+    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return fail(ctx, RT_ERR_INVALID, "tile %d appears twice in the tile list", *std::adjacent_find(sorted.begin(), sorted.end()));
+    void* dev = nullptr;
+    RT_HIP(ctx, hipMalloc(&dev, (size_t)count * sizeof(int32_t)));
+    hipError_t e = uploadNow(dev, tiles, (size_t)count * sizeof(int32_t), ctx->stream);
+    if (e != hipSuccess) {
+        hipFree(dev);
+        return fail(ctx, RT_ERR_DEVICE, "tile list upload: %s", hipGetErrorString(e));
+    }
+    ctx->tileList = static_cast<int32_t*>(dev);
+    ctx->tileListCnt = count;
+    ctx->tileListMax = sorted.back();
+    return RT_OK;
+}
+
+int rt_set_tile_cost_buffer(rt_ctx* ctx, uint32_t* devCost) {
+    if (!ctx) return RT_ERR_INVALID;
+    ctx->tileCost = devCost;
     return RT_OK;
 }
 
@@ -1035,13 +1073,18 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
     p.pitch = pitch;
     p.hitKeys = aux ? aux->hitKeys : nullptr;
     p.counters = aux ? reinterpret_cast<unsigned long long*>(aux->counters) : nullptr;
+    p.tileCost = ctx->tileCost;
     p.tilesX = (opts->width + RT_TILE - 1) / RT_TILE;
     p.tilesY = (opts->height + RT_TILE - 1) / RT_TILE;
     const long long tiles = (long long)p.tilesX * p.tilesY;
     const int tileFirst = aux ? aux->tileFirst : 0;
     const int tileStride = aux && aux->tileStride > 0 ? aux->tileStride : 1;
     if (tileFirst < 0 || tileFirst >= tileStride) return fail(ctx, RT_ERR_INVALID, "tileFirst must be in [0, tileStride)");
-    const long long myTiles = tileFirst < tiles ? (tiles - tileFirst + tileStride - 1) / tileStride : 0;
+    if (ctx->tileList) {
+        if (tileFirst != 0 || tileStride != 1) return fail(ctx, RT_ERR_INVALID, "a call takes its tiles either from rt_set_tile_list or from RtFrameAux.tileFirst / tileStride, not both");
+        if (ctx->tileListMax >= tiles) return fail(ctx, RT_ERR_INVALID, "tile list names tile %d, the frame has %lld tiles", ctx->tileListMax, tiles);
+    }
+    const long long myTiles = ctx->tileList ? ctx->tileListCnt : (tileFirst < tiles ? (tiles - tileFirst + tileStride - 1) / tileStride : 0);
     const int secondary = hd.hasSecondary ? 1 : 0;
     const int budget = secondary && opts->maxDepth > 0 ? ctx->pathBudget : 1;
     const long long nodeCapWanted = myTiles * RT_TILE * RT_TILE * budget * opts->samples;
@@ -1122,7 +1165,7 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
         p.ctxNode = static_cast<int32_t*>(w.ctxNode);
         p.vis = static_cast<unsigned char*>(w.vis);
         p.stackSpill = static_cast<uint2*>(w.stackSpill);
-        p.tileOrder = nullptr;  // row-major: an order table would have to be uploaded into fresh device memory
+        p.tileOrder = ctx->tileList;  // else row-major: an order table would have to be uploaded into fresh device memory
         hipError_t e = (hipError_t)renderKernels(&p, secondary, p.counters ? 1 : 0, ctx->cuCount, ctx->stream, nullptr);
         if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
         ctx->scratchMayOverflow = ctx->scratchMayOverflow || (secondary && opts->maxDepth > 0);
@@ -1178,7 +1221,9 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
     // wavefronts run dry together.  Geometry sits around the image centre far more often than in
     // the corners, so the tiles are handed out centre first.  Which tiles a call renders does not
     // change, only their order in the queue.
-    if (ctx->tileOrderMode == RT_TILE_ORDER_CENTER_OUT) {
+    if (ctx->tileList) {
+        p.tileOrder = ctx->tileList;  // the caller's tiles, in the caller's order
+    } else if (ctx->tileOrderMode == RT_TILE_ORDER_CENTER_OUT) {
         const long long key[6] = {p.tilesX, p.tilesY, tileFirst, tileStride, opts->width, opts->height};
         const void* table = nullptr;
         for (const auto& t : ctx->tileOrders)

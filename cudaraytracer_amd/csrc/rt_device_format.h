@@ -168,6 +168,7 @@ struct FrameParams {
     uint64_t pitch;
     int32_t* hitKeys;
     unsigned long long* counters;
+    uint32_t* tileCost;                      // optional [tilesX * tilesY]: counter launches add each tile's box + triangle tests
     // tile shard
     int32_t tilesX, tilesY;
     int32_t tileFirst, tileStride, tileCnt;  // this call renders tiles tileFirst + k*tileStride, k < tileCnt

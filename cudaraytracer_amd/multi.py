@@ -86,64 +86,153 @@ def share_scene(blob, opts_bytes, camera_floats, rank, world, device, scatter_ga
     return blob, raw[:OPTS_BYTES], np.frombuffer(raw[OPTS_BYTES:], dtype=np.float32).copy()
 
 
+def interleaved_assignment(width, height, world):
+    """Tile t on rank t % world: every rank covers the whole image thinly."""
+    return [tile_ids(width, height, r, world) for r in range(world)]
+
+
+def balanced_assignment(cost, world):
+    """Per-rank tile lists of (nearly) equal COST and equal size, from a per-tile cost table (e.g. the box + triangle
+    tests of the previous frame, rt_set_tile_cost_buffer).  Tiles sorted by falling cost are dealt out in rounds of
+    `world`; within a round the rank that is behind gets the most expensive tile (the classic longest-processing-time
+    rule restricted to equal counts, so that the gather buffers keep their size).  Every list is ordered expensive
+    first, which is also the order the trace kernels should take the tiles in."""
+    cost = torch.as_tensor(cost, dtype=torch.float64).flatten().cpu()
+    n = cost.numel()
+    order = torch.argsort(cost, descending=True, stable=True)
+    lists = [[] for _ in range(world)]
+    load = [0.0] * world
+    for start in range(0, n, world):
+        chunk = order[start:start + world].tolist()
+        ranks = sorted(range(world), key=lambda r: (len(lists[r]), load[r], r))  # the short-handed first, then the least loaded
+        for t, r in zip(chunk, ranks):
+            lists[r].append(t)
+            load[r] += float(cost[t])
+    return [torch.tensor(l, dtype=torch.int64) for l in lists]
+
+
+def quantize8(x):
+    """float -> 8 bit with the reference's dump rule clamp((int)(v * 256), 0, 255) (cudaTracer/PicDumper.h:43-55); NaN -> 0."""
+    return (x * 256.0).nan_to_num(0.0, 255.0, 0.0).clamp_(0.0, 255.0).to(torch.uint8)
+
+
 class TileGather:
-    """Collects the tiles each rank rendered into the full frame on rank 0.  Frame sizes must be multiples of 8.
+    """Collects the tiles each rank rendered into the full frame on rank 0.
+
+    `assignment`: per-rank lists of frame tile indices (default: interleaved, tile t on rank t % world); every tile of
+    the frame must appear exactly once.  Frame sizes need not be multiples of 8: edge tiles travel whole, the frame is
+    cropped when it is assembled.  `quantize=True` sends 8-bit pixels (the PNG dump's rule) instead of floats: a
+    quarter of the bytes over xGMI for a consumer that only wants the picture.
 
     Rank 0 receives every peer's tiles straight into one [world, tiles per rank, 8, 8, c] buffer (one irecv per peer,
-    all in flight together) and interleaves them into tile order with a single strided copy."""
+    all in flight together) and brings them into tile order with a single gather."""
 
-    def __init__(self, width, height, rank, world, device, channels=4, dtype=torch.float32):
-        if width % TILE or height % TILE:
-            raise ValueError("tile gather needs a frame size divisible by 8")
-        self.w, self.h, self.rank, self.world = width, height, rank, world
+    def __init__(self, width, height, rank, world, device, channels=4, dtype=torch.float32, assignment=None, quantize=False):
+        self.w, self.h, self.rank, self.world, self.device = width, height, rank, world, device
         self.tx, self.ty = tile_grid(width, height)
         self.c = channels
         self.n = self.tx * self.ty
-        self.full = self.n // world  # tiles every rank has
-        self.rem = self.n % world    # ranks below this have one more
-        self.mine = tile_ids(width, height, rank, world).to(device)
+        self.quantize = quantize
+        self.dtype = torch.uint8 if quantize else dtype
+        self.buf = self.frame = None
+        self.set_assignment(assignment if assignment is not None else interleaved_assignment(width, height, world))
+
+    def set_assignment(self, assignment):
+        """New per-rank tile lists (e.g. after re-balancing); every rank must call it with the same lists."""
+        if len(assignment) != self.world:
+            raise ValueError("one tile list per rank")
+        device = self.device
+        lists = [torch.as_tensor(a, dtype=torch.int64).flatten() for a in assignment]
+        allt = torch.cat(lists)
+        if allt.numel() != self.n or not torch.equal(torch.sort(allt).values, torch.arange(self.n)):
+            raise ValueError("the tile lists must cover every tile of the frame exactly once")
+        self.counts = [int(l.numel()) for l in lists]
+        self.per = max(self.counts)
+        self.mine = lists[self.rank].to(device)
         # pixel index (row-major over the surface) of every pixel of this rank's tiles, tile by tile: one gather
-        # brings the tiles out of the surface without re-laying out the whole frame first
+        # brings the tiles out of the surface without re-laying out the whole frame first.  Pixels of an edge tile
+        # that lie outside the frame read the nearest pixel inside; they are cropped away on rank 0.
         t = self.mine.view(-1, 1, 1)
-        rows = (t // self.tx) * TILE + torch.arange(TILE, device=device).view(1, TILE, 1)
-        cols = (t % self.tx) * TILE + torch.arange(TILE, device=device).view(1, 1, TILE)
-        self.pixels = (rows * width + cols).reshape(-1)
-        if rank == 0:
-            per = self.full + (1 if self.rem else 0)
-            self.buf = torch.zeros((world, per, TILE, TILE, channels), dtype=dtype, device=device)
-            self.frame = torch.zeros((self.ty, self.tx, TILE, TILE, channels), dtype=dtype, device=device)
+        rows = ((t // self.tx) * TILE + torch.arange(TILE, device=device).view(1, TILE, 1)).clamp_(max=self.h - 1)
+        cols = ((t % self.tx) * TILE + torch.arange(TILE, device=device).view(1, 1, TILE)).clamp_(max=self.w - 1)
+        self.pixels = (rows * self.w + cols).reshape(-1)
+        if self.rank == 0:
+            if self.buf is None or self.buf.shape[1] != self.per:
+                self.buf = torch.zeros((self.world, self.per, TILE, TILE, self.c), dtype=self.dtype, device=device)
+            if self.frame is None:
+                self.frame = torch.zeros((self.ty, self.tx, TILE, TILE, self.c), dtype=self.dtype, device=device)
+            # where tile t sits in the receive buffer (rank r, position k) as one flat index
+            where = torch.empty(self.n, dtype=torch.int64)
+            for r, l in enumerate(lists):
+                where[l] = r * self.per + torch.arange(l.numel())
+            self.where = where.to(device)
 
     def tiles(self, surface):
-        """[h, w, c] surface -> [tiles, 8, 8, c] of this rank's tiles (a copy)."""
-        return surface.view(self.h * self.w, self.c).index_select(0, self.pixels).view(-1, TILE, TILE, self.c)
+        """[h, w, c] surface -> [tiles, 8, 8, c] of this rank's tiles (a copy; 8-bit if the gather quantizes)."""
+        t = surface.view(self.h * self.w, self.c).index_select(0, self.pixels).view(-1, TILE, TILE, self.c)
+        return quantize8(t) if self.quantize else t
 
     def gather(self, surface, assemble=True):
         """Every rank passes its own surface (only its tiles are read).  Rank 0 returns the assembled [h, w, c] frame,
         or, with assemble=False, leaves the tiles as they arrived (rank by rank) for a later assembled() call."""
-        if self.rank == 0:
-            # rank 0's own tiles go straight into their place in the receive buffer
-            own = self.buf[0, : self.pixels.numel() // (TILE * TILE)].view(-1, self.c)
-            torch.index_select(surface.view(self.h * self.w, self.c), 0, self.pixels, out=own)
-        else:
-            mine = self.tiles(surface)
+        mine = self.tiles(surface)
         # Both sides use the batched point-to-point call: on RCCL it puts rank 0's N-1 receives into ONE group, so
         # they run concurrently over the peers' separate xGMI links, and it keeps sender and receiver on the same
         # communicator.
         if self.rank != 0:
-            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine, 0)]):
-                q.wait()
+            if mine.numel():
+                for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, mine.contiguous(), 0)]):
+                    q.wait()
             return None
-        ops = [dist.P2POp(dist.irecv, self.buf[r, :tile_count(self.w, self.h, r, self.world)], r) for r in range(1, self.world)]
+        self.buf[0, : self.counts[0]].copy_(mine)
+        ops = [dist.P2POp(dist.irecv, self.buf[r, : self.counts[r]], r) for r in range(1, self.world) if self.counts[r]]
         reqs = dist.batch_isend_irecv(ops) if ops else []
         for q in reqs:
             q.wait()
         return self.assembled() if assemble else None
 
     def assembled(self):
-        """Rank 0: the latest gathered frame as [h, w, c] (a copy).  The gather leaves the tiles rank by rank
-        (tile k * world + r sits in buf[r, k]); here they are interleaved into tile order and laid out as rows."""
+        """Rank 0: the latest gathered frame as [h, w, c] (a copy): tiles into tile order, rows laid out, edge cropped."""
         flat = self.frame.view(self.n, TILE, TILE, self.c)
-        flat[: self.full * self.world].view(self.full, self.world, TILE, TILE, self.c).copy_(self.buf[:, : self.full].transpose(0, 1))
-        if self.rem:
-            flat[self.full * self.world:] = self.buf[: self.rem, self.full]
-        return self.frame.permute(0, 2, 1, 3, 4).reshape(self.h, self.w, self.c)
+        torch.index_select(self.buf.view(self.world * self.per, TILE, TILE, self.c), 0, self.where, out=flat)
+        full = self.frame.permute(0, 2, 1, 3, 4).reshape(self.ty * TILE, self.tx * TILE, self.c)
+        return full[: self.h, : self.w].contiguous()
+
+
+class FramePipeline:
+    """Frames in flight together with their gathers.  Frame i renders into surface i % F (a swap chain of F
+    surfaces); as soon as F frames are in flight the oldest one is gathered while the newer ones keep rendering, and
+    drain() gathers the ones still in flight.
+
+    render(surface, i)   enqueues frame i (every rank: its own tiles)
+    wait_frame(ago)      orders the gather's stream behind the frame issued `ago` calls ago (no-op on the CPU)
+    gatherer             a TileGather, or None on a single rank
+    to_comm(surface)     surface as the gather's backend wants it (identity on RCCL, .cpu() for a gloo rehearsal)
+    on_gathered(i)       called on every rank after frame i has been gathered (tests look at the frame there)"""
+
+    def __init__(self, surfaces, render, wait_frame=None, gatherer=None, to_comm=None, on_gathered=None):
+        self.surfaces, self.nf = surfaces, len(surfaces)
+        self.render, self.wait_frame, self.gatherer = render, wait_frame, gatherer
+        self.to_comm, self.on_gathered = to_comm, on_gathered
+        self.issued = 0
+
+    def _collect(self, frames_ago):
+        idx = self.issued - 1 - frames_ago
+        if self.wait_frame:
+            self.wait_frame(frames_ago)
+        s = self.surfaces[idx % self.nf]
+        self.gatherer.gather(self.to_comm(s) if self.to_comm else s, assemble=False)
+        if self.on_gathered:
+            self.on_gathered(idx)
+
+    def step(self):
+        self.render(self.surfaces[self.issued % self.nf], self.issued)
+        self.issued += 1
+        if self.gatherer is not None and self.issued >= self.nf:
+            self._collect(self.nf - 1)  # the oldest frame in flight; the newer ones keep running meanwhile
+
+    def drain(self):
+        if self.gatherer is not None:
+            for ago in range(min(self.nf - 1, self.issued) - 1, -1, -1):
+                self._collect(ago)
+        self.issued = 0

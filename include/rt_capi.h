@@ -381,6 +381,19 @@ int rt_set_accumulation(rt_ctx* ctx, void* devSum, size_t sumPitch, uint32_t sam
 #define RT_TILE_ORDER_CENTER_OUT 1
 int rt_set_tile_order(rt_ctx* ctx, int mode);
 
+/* The tiles of the following rt_render calls as an explicit list: `count` indices of 8x8-pixel frame tiles
+ * (row-major over the tile grid, each at most once) in host memory; the list is copied.  The calls render exactly
+ * these tiles, and hand them to the trace kernels in this order (put the expensive ones first).  It replaces
+ * RtFrameAux.tileFirst / tileStride, which must then be 0 / 1; tiles = NULL, count = 0 returns to them.  This is how
+ * a multi-GPU driver gives every GPU a share of equal COST instead of an equal number of tiles
+ * (cudaraytracer_amd/multi.py: balanced_assignment).  The reference has no counterpart. */
+int rt_set_tile_list(rt_ctx* ctx, const int32_t* tiles, int count);
+
+/* Per-tile cost of a frame: `devCost` points to one uint32 per frame tile in device memory (NULL = off).  Calls that
+ * also ask for counters (RtFrameAux.counters: the counting build of the kernels) ADD to entry t the box and triangle
+ * tests of tile t's primary rays and of the shadow rays of their hits.  Clear it with rt_device_zero. */
+int rt_set_tile_cost_buffer(rt_ctx* ctx, uint32_t* devCost);
+
 /* Tuning knob: how many traversal-stack entries per ray are kept in LDS (8 bytes
  * each, 64 rays per wavefront), rounded down to a power of two (at least 2).
  * They form a ring holding the top of the stack; older entries move to a global

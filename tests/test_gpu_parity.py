@@ -208,6 +208,60 @@ def test_tile_shards_compose_the_frame(gpu_ctx, world):
         gpu_ctx.free_scene(dscene)
 
 
+@pytest.mark.parametrize("world", [1, 3])
+def test_cost_balanced_tile_lists_compose_the_frame(gpu_ctx, world):
+    """A counter frame books every tile's box + triangle tests; balanced_assignment turns them into per-rank tile lists
+    of equal cost; rendered list by list (rt_set_tile_list) the frame is the one rendered whole, and the lists' measured
+    costs are closer together than those of the interleaved shards."""
+    from cudaraytracer_amd import multi as mg
+
+    w, h = 203, 117  # ragged tiles
+    scene = rt.HostScene("soup", w, h, 30000, 2, 0, tight_bvh=True)
+    dscene = gpu_ctx.upload(scene)
+    tx, ty = mg.tile_grid(w, h)
+    surf, pitch = gpu_ctx.surface(w, h)
+    keys = gpu_ctx.alloc(w * h * 16)
+    cnt = gpu_ctx.alloc(rt.RT_COUNTER_CNT * 8)
+    cost = gpu_ctx.alloc(tx * ty * 4)
+    try:
+        gpu_ctx.set_tile_cost_buffer(cost)
+        full = gpu_ctx.render_frame(scene, dscene, want_keys=True, want_counters=True)
+        costs = gpu_ctx.download(cost, (tx * ty,), np.uint32).astype(np.int64)
+        # depth 0: every ray is a primary ray or the shadow ray of a primary hit, so the tiles' costs add up to the frame's tests
+        assert int(costs.sum()) == full[2]["node"] + full[2]["tri"]
+        assert costs.min() > 0 and costs.max() > 3 * np.median(costs)  # the soup's centre is far more expensive than its rim
+        lists = mg.balanced_assignment(costs, world)
+        spread = lambda ls: max(int(costs[np.asarray(l)].sum()) for l in ls) - min(int(costs[np.asarray(l)].sum()) for l in ls)  # noqa: E731
+        if world > 1:
+            assert spread(lists) <= spread(mg.interleaved_assignment(w, h, world))
+        gpu_ctx.set_tile_cost_buffer(None)
+        gpu_ctx.zero(surf, pitch * h)
+        gpu_ctx.zero(keys, w * h * 16)
+        gpu_ctx.zero(cnt, rt.RT_COUNTER_CNT * 8)
+        for l in lists:
+            gpu_ctx.set_tile_list(l.numpy())
+            gpu_ctx.render(dscene, scene.opts, scene.camera, surf, pitch, keys, cnt)
+        gpu_ctx.sync()
+        assert np.array_equal(gpu_ctx.download(keys, (h, w, 4), np.int32), full[1])
+        assert np.array_equal(gpu_ctx.download_surface(surf, pitch, w, h), full[0], equal_nan=True)
+        c = gpu_ctx.download(cnt, (rt.RT_COUNTER_CNT,), np.uint64)
+        assert {n: int(c[i]) for i, n in enumerate(rt.RT_COUNTER_NAMES)} == full[2]
+        # a list and an arithmetic shard in one call, a tile outside the frame, a tile twice: refused
+        with pytest.raises(rt.RtError, match="not both"):
+            gpu_ctx.render(dscene, scene.opts, scene.camera, surf, pitch, None, None, 1, 2)
+        gpu_ctx.set_tile_list([0, tx * ty])
+        with pytest.raises(rt.RtError, match="tiles"):
+            gpu_ctx.render(dscene, scene.opts, scene.camera, surf, pitch)
+        with pytest.raises(rt.RtError, match="twice"):
+            gpu_ctx.set_tile_list([3, 5, 3])
+    finally:
+        gpu_ctx.set_tile_list(None)
+        gpu_ctx.set_tile_cost_buffer(None)
+        for p in (surf, keys, cnt, cost):
+            gpu_ctx.free(p)
+        gpu_ctx.free_scene(dscene)
+
+
 @pytest.mark.parametrize("in_flight,frames", [(3, 6), (16, 40)])
 def test_frames_in_flight_overlap_without_mixing(gpu_ctx, in_flight, frames):
     """Several frames in flight, frames of two different scenes into their own surfaces (twice round the slots and
