@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--reference-bvh", action="store_true", help="build BVHs with the reference's FLT_MIN-clamped boxes")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--tile-balance", choices=("cost", "interleaved"), default="cost",
+                    help="N > 1: tiles per GPU by measured cost (equal box + triangle tests per GPU) or tile t on GPU t %% N")
     ap.add_argument("--no-others", action="store_true", help="skip the other workloads and the FAST build (headline only)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="consecutive frames that may overlap on a GPU (1 = strictly in order, at most 16; default 12)")
@@ -250,6 +252,7 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -306,17 +309,37 @@ def main():
     if multi:
         # frame i renders into surface i % F; the oldest frame in flight is gathered to rank 0 (where it then sits as
         # 8x8-pixel tiles, rank by rank; TileGather.assembled() lays it out as rows) while the newer ones keep rendering
-        pipe = mg.FramePipeline(surfaces, lambda s, i: ctx.render(dscene, opts, camera_ref, s.data_ptr(), pitch, None, None, rank, world),
+        pipe = mg.FramePipeline(surfaces, lambda s, i: ctx.render(dscene, opts, camera_ref, s.data_ptr(), pitch, None, None, *shard),
                                 lambda ago: ctx.stream_wait_frame(stream.cuda_stream, ago), gatherer, (lambda s: s.to(comm_dev)))
     else:
         pipe = mg_single(surfaces, lambda s: ctx.render(dscene, opts, camera_ref, s.data_ptr(), pitch))
     step, drain = pipe.step, pipe.drain
 
     # ---- exact ray / test counts of the frame (untimed counter build) ----
+    shard = [rank, world]  # tileFirst, tileStride of every render call; [0, 1] once a tile list is set
+    tile_cost = None
+    if multi and args.tile_balance == "cost":
+        tile_cost = torch.zeros(gatherer.n, dtype=torch.int32, device=dev)
+        ctx.set_tile_cost_buffer(tile_cost.data_ptr())
     cnt_buf = counters_of(ctx, dscene, opts, camera_ref, surface.data_ptr(), pitch, rank, world)
     if multi:
         cnt_buf = cnt_buf.to(comm_dev)
         dist.all_reduce(cnt_buf)
+    balance = None
+    if tile_cost is not None:
+        # Every rank measured its interleaved share of the tiles; summed, that is the frame's cost map.  Every rank
+        # derives the same lists from it: equal tile counts, equal box + triangle tests, expensive tiles first.
+        ctx.set_tile_cost_buffer(None)
+        cost_all = tile_cost.to(comm_dev).to(torch.int64)
+        dist.all_reduce(cost_all)
+        cost_all = cost_all.cpu()
+        lists = mg.balanced_assignment(cost_all, world)
+        loads = [int(cost_all[l].sum()) for l in lists]
+        inter = [int(cost_all[l].sum()) for l in mg.interleaved_assignment(w, h, world)]
+        balance = {"max_over_mean_cost_balanced": max(loads) / (sum(loads) / world), "max_over_mean_cost_interleaved": max(inter) / (sum(inter) / world)}
+        ctx.set_tile_list(lists[rank].numpy())
+        gatherer.set_assignment(lists)
+        shard[:] = [0, 1]
     cnt = {name: int(cnt_buf[i].item()) for i, name in enumerate(rt.RT_COUNTER_NAMES)}
     rays = cnt["primary"] + cnt["shadow"]
 
@@ -367,12 +390,12 @@ def main():
         ctx.sync()
         ctx.set_frames_in_flight(1)
         for _ in range(2):
-            ctx.render(dscene, opts, camera_ref, surfaces[0].data_ptr(), pitch, None, None, rank, world)
+            ctx.render(dscene, opts, camera_ref, surfaces[0].data_ptr(), pitch, None, None, *shard)
         ctx.sync()
         ctx.timing_reset()
         t0 = time.perf_counter()
         for _ in range(frames):
-            ctx.render(dscene, opts, camera_ref, surfaces[0].data_ptr(), pitch, None, None, rank, world)
+            ctx.render(dscene, opts, camera_ref, surfaces[0].data_ptr(), pitch, None, None, *shard)
         ctx.sync()
         wall = (time.perf_counter() - t0) / frames * 1e3
         k_ms, st, n = ctx.timing_read_stages()
@@ -391,8 +414,12 @@ def main():
     gather_check = None
     if multi and rank == 0:
         whole = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+        if tile_cost is not None:
+            ctx.set_tile_list(None)
         ctx.render(dscene, opts, camera_ref, whole.data_ptr(), pitch, None, None, 0, 1)
         ctx.sync()
+        if tile_cost is not None:
+            ctx.set_tile_list(lists[0].numpy())
         torch.cuda.synchronize(dev)
         a, b = gatherer.assembled().to(dev), whole
         differing = int(((a != b) & ~(torch.isnan(a) & torch.isnan(b))).any(dim=2).sum().item())
@@ -405,10 +432,10 @@ def main():
         fast_keys = torch.zeros((h, w, 4), dtype=torch.int32, device=dev)
         exact_frame = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
         ctx.set_frames_in_flight(1)
-        ctx.render(dscene, opts, camera_ref, exact_frame.data_ptr(), pitch, exact_keys.data_ptr(), None, rank, world)
+        ctx.render(dscene, opts, camera_ref, exact_frame.data_ptr(), pitch, exact_keys.data_ptr(), None, *shard)
         ctx.sync()
         ctx.set_arithmetic(True)
-        ctx.render(dscene, opts, camera_ref, surfaces[0].data_ptr(), pitch, fast_keys.data_ptr(), None, rank, world)
+        ctx.render(dscene, opts, camera_ref, surfaces[0].data_ptr(), pitch, fast_keys.data_ptr(), None, *shard)
         ctx.sync()
         torch.cuda.synchronize(dev)
         f_elapsed, _, _ = timed_region(max(args.steps // 2, 10), 2)
@@ -500,7 +527,10 @@ def main():
                                    f"{'reference (FLT_MIN-clamped)' if args.reference_bvh else 'tight-bounds'} median-split BVH; "
                                    "EXACT build of the kernels (bit-identical to the reference's formulas)",
                        "rays_per_frame": rays, "primary": cnt["primary"], "shadow": cnt["shadow"],
-                       "tile_sharding": f"8x8 tiles, tile t on GPU t % {world}, gathered to GPU0 each frame" if multi else "single GPU",
+                       "tile_sharding": ("single GPU" if not multi else
+                                         f"8x8 tiles, per-GPU lists of equal measured cost (box + triangle tests of a counter frame), gathered to GPU0 each frame"
+                                         if balance else f"8x8 tiles, tile t on GPU t % {world}, gathered to GPU0 each frame"),
+                       "tile_balance": balance,
                        "frames_in_flight": nf,
                        "frame_latency_ms_with_frames_in_flight": in_flight_stage[0],
                        "in_order": {"ms_per_frame": frame_ms, "wall_ms_per_frame": alone_wall, "Mrays_per_s": rays / alone_wall / 1e3,
