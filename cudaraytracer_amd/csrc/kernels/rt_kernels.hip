@@ -656,6 +656,35 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     const float4 L0 = p[0], L1 = p[1], L2 = p[2], L3 = p[3];
                     STAMP(2);  // node step: child pair arrived
                     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
+#ifdef RT_X_VALU  // sensitivity experiment: RT_X_VALU extra vector instructions per node step, in 8 independent chains
+                    {
+                        float x0 = o.x, x1 = o.y, x2 = o.z, x3 = inv.x, x4 = inv.y, x5 = inv.z, x6 = tMax, x7 = L0.x;
+#pragma unroll
+                        for (int i = 0; i < RT_X_VALU / 8; ++i)
+                            asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
+                                         "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8"
+                                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                                         : "v"(L1.x));
+                        asm volatile("" ::"v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7));
+                    }
+#endif
+#ifdef RT_X_CMP  // sensitivity experiment: extra compare + select pairs per node step
+                    {
+                        float x0 = o.x, x1 = o.y;
+#pragma unroll
+                        for (int i = 0; i < RT_X_CMP / 2; ++i)
+                            asm volatile("v_cmp_lt_f32 vcc, %0, %2\n v_cndmask_b32 %1, %1, %2, vcc" : "+v"(x0), "+v"(x1) : "v"(L1.x) : "vcc");
+                        asm volatile("" ::"v"(x0), "v"(x1));
+                    }
+#endif
+#ifdef RT_X_SALU  // sensitivity experiment: extra scalar instructions per node step
+                    {
+                        unsigned s0 = (unsigned)level;
+#pragma unroll
+                        for (int i = 0; i < RT_X_SALU; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(s0) : : "scc");
+                        asm volatile("" ::"s"(s0));
+                    }
+#endif
                     float t0, t1;
                     bool g0, g1;
 #ifdef RT_FAST

@@ -25,6 +25,7 @@ ap.add_argument("--reference-bvh", action="store_true")
 ap.add_argument("--lds-stack", type=int, default=0)
 ap.add_argument("--frames-in-flight", type=int, default=0)
 ap.add_argument("--waves", type=int, default=0)
+ap.add_argument("--cost-order", action="store_true", help="tiles in order of falling cost, measured by a counter frame (rt_set_tile_list)")
 ap.add_argument("--fast", action="store_true", help="the FAST build of the kernels (rt_set_arithmetic)")
 ap.add_argument("--tile-order", type=int, default=-1)
 ap.add_argument("--device-bvh", action="store_true")
@@ -89,18 +90,30 @@ with rt.Context(0) as ctx:
             for i, n in enumerate(names):
                 cyc, k = int(big[base + 2 * i]), int(big[base + 2 * i + 1])
                 print(f"    {n:24s} {100.0*cyc/max(tot,1):5.1f} %  {k:9d} times  {cyc/max(k,1):8.1f} cycles each")
+    if a.cost_order:
+        tx, ty = (a.width + 7) // 8, (a.height + 7) // 8
+        cost = ctx.alloc(tx * ty * 4)
+        ctx.set_tile_cost_buffer(cost)
+        ctx.render(ds, scene.opts, scene.camera, surf, pitch, None, cnt)
+        ctx.sync()
+        ctx.set_tile_cost_buffer(None)
+        costs = ctx.download(cost, (tx * ty,), np.uint32).astype(np.int64)
+        order = np.argsort(-costs, kind="stable")[:: 1]
+        order = order[a.stride - 1:: a.stride] if a.stride > 1 else order
+        ctx.set_tile_list(order)
+        print(f"  cost order: most expensive tile {costs.max()} tests, median {int(np.median(costs))}, cheapest {costs.min()}")
     rays = c["primary"] + c["shadow"] + c["secondary"]
     nf = max(a.frames_in_flight, 1)
     surfs = [surf] + [ctx.surface(a.width, a.height)[0] for _ in range(nf - 1)]
     for i in range(2 * nf):
-        ctx.render(ds, scene.opts, scene.camera, surfs[i % nf], pitch, None, None, 0, a.stride)
+        ctx.render(ds, scene.opts, scene.camera, surfs[i % nf], pitch, None, None, 0, 1 if a.cost_order else a.stride)
     ctx.sync()
     ctx.timing_reset()
     t0 = time.perf_counter()
     issue = 0.0
     for i in range(a.steps):
         ti = time.perf_counter()
-        ctx.render(ds, scene.opts, scene.camera, surfs[i % nf], pitch, None, None, 0, a.stride)
+        ctx.render(ds, scene.opts, scene.camera, surfs[i % nf], pitch, None, None, 0, 1 if a.cost_order else a.stride)
         issue += time.perf_counter() - ti
     print(f"host time inside rt_render: {issue/a.steps*1e3:.3f} ms per frame")
     ctx.sync()
