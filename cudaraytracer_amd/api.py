@@ -18,17 +18,21 @@ class HostScene:
     name: cubes | soup | heightfield | mixed | barrel
     tight_bvh: start BVH box unions from a true empty box instead of the
     reference's FLT_MIN-clamped one (same hits except ties, far fewer tests).
+    sah_bvh: cut mesh BVHs by the binned surface-area heuristic instead of the
+    reference's median cut (host build; same hits except ties, fewer tests);
+    leaf_threshold: most triangles in a leaf (0: 10 for the median cut, 8 for
+    the surface-area cut).
     """
 
     def __init__(self, name, width, height, size=0, lights=0, max_depth=0, asset_dir=None, tight_bvh=False, device_bvh=False,
-                 _handle=None):
+                 sah_bvh=False, leaf_threshold=0, _handle=None):
         self.lib = N.load()
         if _handle is not None:  # a scene some other harness call built (Experiment.scene)
             self.h = _handle
             self.name = name
             return
         self.h = self.lib.rth_scene_create(name.encode(), width, height, size, lights, max_depth,
-                                           asset_dir.encode() if asset_dir else None, (1 if tight_bvh else 0) | (2 if device_bvh else 0))
+                                           asset_dir.encode() if asset_dir else None, (1 if tight_bvh else 0) | (2 if device_bvh else 0) | (8 if sah_bvh else 0) | ((leaf_threshold & 0xff) << 8))
         if not self.h:
             raise RtError(self.lib.rth_last_error().decode())
         self.name = name

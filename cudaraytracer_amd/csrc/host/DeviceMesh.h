@@ -49,13 +49,15 @@ class DeviceMesh {
     Shape shape;
 
     BVH::BoundsMode boundsMode = BVH::REFERENCE_BOUNDS;
+    BVH::SplitRule splitRule = BVH::MEDIAN_CUT;
+    int leafThreshold = 10;
     bool bvhOnDevice = false;  // nodes stay empty; rt_scene_upload builds the BVH on the GPU
     BoundingBox rootBox;       // box of the whole mesh (object space)
 
     DeviceMesh(std::vector<Vertex> vertices, std::vector<int> indices, int /*triCnt*/, TextureSource diffuse,
                TextureSource normals, TextureSource specular, Texture::AddressingMode mode, Material material,
                Mat44f transformation, BVH::BuildOptions build = BVH::BuildOptions())
-        : boundsMode(build.bounds), bvhOnDevice(build.onDevice) {
+        : boundsMode(build.bounds), splitRule(build.split), leafThreshold(build.leafThreshold), bvhOnDevice(build.onDevice) {
         prepareGeometry(std::move(vertices), std::move(indices));
         createShape(diffuse, normals, specular, mode, material, transformation);
     }
@@ -64,7 +66,7 @@ class DeviceMesh {
     // (cudaTracer/CudaMesh.h:37-47).
     DeviceMesh(const model::Model& model, Material material, Mat44f transformation,
                BVH::BuildOptions build = BVH::BuildOptions())
-        : boundsMode(build.bounds), bvhOnDevice(build.onDevice) {
+        : boundsMode(build.bounds), splitRule(build.split), leafThreshold(build.leafThreshold), bvhOnDevice(build.onDevice) {
         prepareGeometry(model.getVertices(), model.getIndices());
         if (model.getMaterials().empty()) throw std::invalid_argument("DeviceMesh: model without material");
         const model::Material& m = model.getMaterials()[0];
@@ -96,10 +98,17 @@ class DeviceMesh {
             bvhDepth = BVH::medianTreeDepth((int)triangles.size(), 10);
             return;
         }
-        BVH::BvhFactory<Triangle> bvh(vertices, tris, 10, boundsMode);
+        if (splitRule != BVH::MEDIAN_CUT) {
+            // the tangent frame a shared vertex ends up with depends on the order the faces are visited in: keep the
+            // order of the median-cut tree for that, whatever tree the rays walk
+            BVH::BvhFactory<Triangle> referenceOrder(vertices, tris, 10, boundsMode);
+            triangles = std::move(referenceOrder.orderedPrims);
+            generateTangents();
+        }
+        BVH::BvhFactory<Triangle> bvh(vertices, tris, leafThreshold, boundsMode, splitRule);
         triangles = std::move(bvh.orderedPrims);
         triangleSource = std::move(bvh.orderedIdx);
-        generateTangents();
+        if (splitRule == BVH::MEDIAN_CUT) generateTangents();
         nodes = std::move(bvh.nodes);
         bvhDepth = bvh.depth;
         rootBox = nodes[0].bb;

@@ -348,6 +348,16 @@ struct rth_scene {
     }
 };
 
+// flags of rth_scene_create / rth_experiment_scene: bit 0 tight BVH bounds, bit 1 mesh BVHs built on the device,
+// bit 3 mesh BVHs cut by the binned surface-area heuristic (host build), bits 8..15 leaf threshold (0: 10, the
+// reference's, for the median cut; 8 for the surface-area cut)
+BuildOptions buildOptionsOf(int flags) {
+    const BVH::SplitRule rule = (flags & 8) ? BVH::BINNED_SAH : BVH::MEDIAN_CUT;
+    int threshold = (flags >> 8) & 0xff;
+    if (threshold == 0) threshold = rule == BVH::BINNED_SAH ? 8 : 10;
+    return BuildOptions((flags & 1) ? BVH::TIGHT_BOUNDS : BVH::REFERENCE_BOUNDS, (flags & 2) != 0, rule, threshold);
+}
+
 extern "C" {
 
 const char* rth_last_error(void) { return g_error.c_str(); }
@@ -358,7 +368,7 @@ const char* rth_last_error(void) { return g_error.c_str(); }
 rth_scene* rth_scene_create(const char* name, int width, int height, int size, int lightCnt, int maxDepth, const char* assetDir,
                             int flags) {
     try {
-        const BuildOptions bm((flags & 1) ? BVH::TIGHT_BOUNDS : BVH::REFERENCE_BOUNDS, (flags & 2) != 0);
+        const BuildOptions bm = buildOptionsOf(flags);
         const std::string n = name ? name : "";
         const std::string assets = assetDir ? assetDir : "";
         std::unique_ptr<RayTracer> rt;
@@ -495,7 +505,7 @@ rth_scene* rth_experiment_scene(rth_experiment* e, int idx, const char* assetDir
         if (idx < 0 || idx >= e->reader->experiment.phaseCnt) throw std::invalid_argument("rth_experiment_scene: no such phase");
         Options opts = e->reader->experiment.phases[idx].opts;
         if (flags & 4) setView(opts, opts.device.width, opts.device.height, opts.host.fov);
-        const BuildOptions bm((flags & 1) ? BVH::TIGHT_BOUNDS : BVH::REFERENCE_BOUNDS, (flags & 2) != 0);
+        const BuildOptions bm = buildOptionsOf(flags);
         std::unique_ptr<RayTracer> rt = buildPhase(opts, assetDir ? assetDir : "", bm);
         auto* h = new rth_scene();
         h->rt = std::move(rt);

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/rt_capi.h"
+#include "host/BVH.h"
 #include "rt_device_format.h"
 
 #ifndef RT_LDS_STACK_DEFAULT
@@ -887,6 +888,38 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
     sc->bytes = host.size();
     std::memcpy(&sc->header, host.data(), sizeof(BlobHeader));
     return sc;
+}
+
+int rt_mesh_bvh_build(const RtVertex* vertices, int vertexCnt, const RtTriangle* triangles, int triangleCnt, int splitRule,
+                      int leafThreshold, int tightBounds, RtLinearNode* nodes, int nodeCapacity, int* nodeCnt, int32_t* order) {
+    auto bad = [](const char* what) {
+        g_createError = what;
+        return RT_ERR_INVALID;
+    };
+    if (!vertices || !triangles || !nodes || !nodeCnt || !order || vertexCnt < 1 || triangleCnt < 1) return bad("rt_mesh_bvh_build: null or empty argument");
+    if (splitRule != RT_BVH_MEDIAN_CUT && splitRule != RT_BVH_BINNED_SAH) return bad("rt_mesh_bvh_build: unknown split rule");
+    if (leafThreshold < 1 || leafThreshold > RT_REF_MAX_LEAF_PRIMS) return bad("rt_mesh_bvh_build: leaf threshold outside 1..RT_REF_MAX_LEAF_PRIMS");
+    for (int t = 0; t < triangleCnt; ++t)
+        for (int c = 0; c < 3; ++c)
+            if (triangles[t].i[c] < 0 || triangles[t].i[c] >= vertexCnt) return bad("rt_mesh_bvh_build: vertex index out of range");
+    try {
+        static_assert(sizeof(rt::Vertex) == sizeof(RtVertex) && sizeof(rt::Triangle) == sizeof(RtTriangle), "host mirrors of the C structs");
+        const std::vector<rt::Vertex> v(reinterpret_cast<const rt::Vertex*>(vertices), reinterpret_cast<const rt::Vertex*>(vertices) + vertexCnt);
+        const std::vector<rt::Triangle> t(reinterpret_cast<const rt::Triangle*>(triangles), reinterpret_cast<const rt::Triangle*>(triangles) + triangleCnt);
+        rt::BVH::BvhFactory<rt::Triangle> bvh(v, t, leafThreshold, tightBounds ? rt::BVH::TIGHT_BOUNDS : rt::BVH::REFERENCE_BOUNDS,
+                                               splitRule == RT_BVH_BINNED_SAH ? rt::BVH::BINNED_SAH : rt::BVH::MEDIAN_CUT);
+        *nodeCnt = (int)bvh.nodes.size();
+        if ((int)bvh.nodes.size() > nodeCapacity) {
+            g_createError = "rt_mesh_bvh_build: node array too small (2 * triangleCnt - 1 always fits)";
+            return RT_ERR_LIMIT;
+        }
+        std::memcpy(nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(RtLinearNode));
+        std::memcpy(order, bvh.orderedIdx.data(), bvh.orderedIdx.size() * sizeof(int32_t));
+        return RT_OK;
+    } catch (const std::exception& e) {
+        g_createError = std::string("rt_mesh_bvh_build: ") + e.what();
+        return RT_ERR_INVALID;
+    }
 }
 
 int rt_set_device_bvh(rt_ctx* ctx, int threshold, int tightBounds) {

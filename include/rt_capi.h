@@ -353,6 +353,21 @@ int rt_check_workspace_guards(rt_ctx* ctx);
  * a range into one leaf of any size); build that mesh's BVH on the host.  Defaults: threshold 10, tight bounds. */
 int rt_set_device_bvh(rt_ctx* ctx, int threshold, int tightBounds);
 
+/* Mesh BVH built on the host, for callers that hand their meshes over WITH nodes (RtMesh.nodes).  Host code only: no
+ * context, no GPU.  RT_BVH_MEDIAN_CUT is the reference's builder (cudaTracer/BVH.h:104-181, called with threshold 10
+ * by cudaTracer/CudaMesh.h:58): same nodes, same leaf order.  RT_BVH_BINNED_SAH has no counterpart in the reference:
+ * every range is cut where the surface-area heuristic over 32 centroid bins per axis is lowest (median cut when no bin
+ * boundary separates the range), so the tree is not balanced and may be deeper than ceil(log2(n / threshold)); hits
+ * are the same as with the reference's tree except for equal-distance ties, which depend on visiting order.
+ * `leafThreshold` (1..63) is the most triangles a leaf gets unless their centroids coincide.  `order[k]` receives the
+ * index (into `triangles`) of the triangle that belongs in leaf slot k: the caller hands RtMesh.triangles over in that
+ * order.  `nodes` must hold `nodeCapacity` entries; 2 * triangleCnt - 1 always suffice.
+ * Returns RT_ERR_INVALID / RT_ERR_LIMIT with the message in rt_last_error(NULL). */
+#define RT_BVH_MEDIAN_CUT 0
+#define RT_BVH_BINNED_SAH 1
+int rt_mesh_bvh_build(const RtVertex* vertices, int vertexCnt, const RtTriangle* triangles, int triangleCnt, int splitRule,
+                      int leafThreshold, int tightBounds, RtLinearNode* nodes, int nodeCapacity, int* nodeCnt, int32_t* order);
+
 /* Seed of the sub-pixel jitter used with samples > 1 (default 1234, the seed the reference gives curand,
  * cudaTracer/Main.cu:127).  Change it per frame to accumulate independent samples over frames. */
 int rt_set_sample_seed(rt_ctx* ctx, uint32_t seed);

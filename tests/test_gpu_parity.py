@@ -37,6 +37,16 @@ def test_frame_matches_oracle(gpu_ctx, oracle, name, w, h, size, lights, depth, 
     assert np.array_equal(rgba, rgba2, equal_nan=True)
 
 
+@pytest.mark.parametrize("name,w,h,size,lights,depth", [("soup", 192, 108, 200000, 1, 0), ("heightfield", 160, 96, 20000, 2, 0), ("mixed", 160, 120, 0, 4, 3)])
+def test_surface_area_tree_frame_matches_oracle(gpu_ctx, oracle, name, w, h, size, lights, depth):
+    """Mesh BVHs cut by the binned surface-area heuristic: unbalanced trees, deeper stacks, the same walk on both sides."""
+    scene = rt.HostScene(name, w, h, size, lights, depth, tight_bvh=True, sah_bvh=True)
+    ref_rgba, ref_keys, ref_cnt = oracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=8, shadow_any_hit=True)
+    rgba, keys, cnt = gpu_ctx.render_frame(scene, want_keys=True, want_counters=True)
+    assert_parity(rgba, keys, ref_rgba, ref_keys)
+    assert cnt == ref_cnt, (cnt, ref_cnt)
+
+
 # ---- OBJ + PNG assets: reader, decoder, tangents, CLAMP and WRAP texturing of 1024x1024 maps -----------------
 @pytest.mark.parametrize("name,w,h,lights,depth", [("barrel", 200, 150, 4, 2), ("mixed", 160, 120, 10, 3), ("barrel", 97, 61, 1, 0)])
 def test_asset_scenes_match_oracle(gpu_ctx, oracle, synthetic_assets, name, w, h, lights, depth):

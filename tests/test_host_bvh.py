@@ -79,6 +79,109 @@ def test_reference_bounds_are_clamped_at_flt_min(rtlib, oracle):
     assert np.all(tight[:, 3:6] < 0)
 
 
+def capi_build(rtlib, verts, tris, rule, threshold, tight):
+    n = len(tris)
+    nodes = (N.RtLinearNode * (2 * n))()
+    cnt = C.c_int()
+    order = (C.c_int * n)()
+    rc = rtlib.rt_mesh_bvh_build(C.addressof(verts), len(verts), C.addressof(tris), n, rule, threshold, tight, C.addressof(nodes), 2 * n,
+                                 C.byref(cnt), C.addressof(order))
+    assert rc == 0, rtlib.rt_last_error(None)
+    return nodes, cnt.value, list(order)
+
+
+def clustered_mesh(n_tris, seed):
+    """Triangles in a few dense clumps of very different size, plus a thin uniform haze: far from a median cut's ideal."""
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(-40, 40, (6, 3))
+    spread = np.array([0.3, 0.5, 1.0, 2.0, 4.0, 30.0])
+    verts = (N.RtVertex * (3 * n_tris))()
+    tris = (N.RtTriangle * n_tris)()
+    for t in range(n_tris):
+        k = int(rng.integers(0, 6))
+        c = centres[k] + rng.normal(0, spread[k], 3)
+        for j in range(3):
+            p = c + rng.uniform(-0.2, 0.2, 3)
+            for a in range(3):
+                verts[3 * t + j].position[a] = float(np.float32(p[a]))
+            tris[t].i[j] = 3 * t + j
+    return verts, tris
+
+
+def walk(nodes, cnt, order, verts, tris, threshold):
+    """Checks the flattened tree (first child at self + 1, second by index) and returns its surface-area cost."""
+    pos = np.array([[verts[i].position[a] for a in range(3)] for i in range(len(verts))], dtype=np.float32)
+    seen, cost, visited = [], 0.0, 0
+    area = lambda lo, hi: float(np.prod([1.0]) * ((hi - lo)[0] * (hi - lo)[1] + (hi - lo)[1] * (hi - lo)[2] + (hi - lo)[2] * (hi - lo)[0]))
+    stack = [0]
+    while stack:
+        i = stack.pop()
+        visited += 1
+        nd = nodes[i]
+        lo, hi = np.array(nd.bbmin[:], dtype=np.float32), np.array(nd.bbmax[:], dtype=np.float32)
+        if nd.primCnt:
+            assert nd.primCnt <= threshold
+            slots = range(nd.offset, nd.offset + nd.primCnt)
+            p = np.concatenate([pos[[tris[order[k]].i[c] for c in range(3)]] for k in slots])
+            assert np.array_equal(p.min(0), lo) and np.array_equal(p.max(0), hi), "leaf box is not the box of its triangles"
+            seen.extend(order[k] for k in slots)
+            cost += area(lo, hi) * nd.primCnt
+        else:
+            a, b = nodes[i + 1], nodes[nd.offset]
+            assert nd.offset > i + 1 and nd.axis in (0, 1, 2)
+            assert np.array_equal(np.minimum(a.bbmin[:], b.bbmin[:]).astype(np.float32), lo)
+            assert np.array_equal(np.maximum(a.bbmax[:], b.bbmax[:]).astype(np.float32), hi)
+            cost += area(lo, hi)
+            stack += [i + 1, nd.offset]
+    assert visited == cnt and sorted(seen) == list(range(len(tris)))
+    return cost
+
+
+def test_capi_median_build_is_the_host_builder(rtlib, oracle):
+    verts, tris = random_mesh(700, seed=21)
+    for tight in (0, 1):
+        nodes, cnt, order = capi_build(rtlib, verts, tris, 0, 10, tight)
+        ref = build_both(rtlib, oracle, verts, tris, 10, tight)["oracle"]
+        assert bytes(nodes)[: 32 * cnt] == ref[0] and order == ref[1] and cnt == ref[2]
+
+
+def test_surface_area_tree_is_valid_and_cheaper(rtlib):
+    verts, tris = clustered_mesh(3000, seed=4)
+    median = walk(*capi_build(rtlib, verts, tris, 0, 8, 1), verts, tris, 8)
+    sah = walk(*capi_build(rtlib, verts, tris, 1, 8, 1), verts, tris, 8)
+    print("surface-area cost: median cut", median, "binned SAH", sah)
+    assert sah < 0.8 * median
+
+
+def test_bvh_build_rejects_bad_arguments(rtlib):
+    verts, tris = random_mesh(4, seed=1)
+    nodes = (N.RtLinearNode * 8)()
+    cnt = C.c_int()
+    order = (C.c_int * 4)()
+    args = lambda **kw: [kw.get("v", C.addressof(verts)), 12, C.addressof(tris), kw.get("n", 4), kw.get("rule", 1), kw.get("thr", 1), 1,
+                         C.addressof(nodes), kw.get("cap", 8), C.byref(cnt), C.addressof(order)]
+    assert rtlib.rt_mesh_bvh_build(*args(v=None)) == -1
+    assert rtlib.rt_mesh_bvh_build(*args(rule=7)) == -1
+    assert rtlib.rt_mesh_bvh_build(*args(thr=0)) == -1
+    assert rtlib.rt_mesh_bvh_build(*args(cap=3)) == -3 and b"node array too small" in rtlib.rt_last_error(None)
+    tris[2].i[1] = 99
+    assert rtlib.rt_mesh_bvh_build(*args()) == -1 and b"vertex index" in rtlib.rt_last_error(None)
+
+
+@pytest.mark.parametrize("name,size", [("soup", 3000), ("mixed", 0), ("heightfield", 5000)])
+def test_surface_area_trees_give_the_same_image(oracle, name, size):
+    """Same hit keys and the same radiance with mesh BVHs cut by the surface-area heuristic (no exact ties in these
+    scenes: nothing is coplanar along a ray), with fewer or as many box tests."""
+    w, h = 64, 40
+    a = rt.HostScene(name, w, h, size, 2, 2, tight_bvh=True)
+    b = rt.HostScene(name, w, h, size, 2, 2, tight_bvh=True, sah_bvh=True)
+    ra, ka, ca = oracle.render(a.desc, a.opts, a.camera, w, h, threads=4)
+    rb, kb, cb = oracle.render(b.desc, b.opts, b.camera, w, h, threads=4)
+    assert np.array_equal(ka, kb)
+    assert np.array_equal(ra, rb, equal_nan=True)
+    print(name, "box tests", ca["node"], "->", cb["node"], "triangle tests", ca["tri"], "->", cb["tri"])
+
+
 @pytest.mark.parametrize("name,size", [("cubes", 6), ("soup", 3000), ("mixed", 0)])
 def test_image_does_not_depend_on_the_bvh(oracle, name, size):
     """Tight vs reference bounds, and BVH vs linear scans (useSceneBvh / useMeshBvhs off), give the same hits."""

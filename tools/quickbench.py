@@ -29,6 +29,8 @@ ap.add_argument("--cost-order", action="store_true", help="tiles in order of fal
 ap.add_argument("--fast", action="store_true", help="the FAST build of the kernels (rt_set_arithmetic)")
 ap.add_argument("--tile-order", type=int, default=-1)
 ap.add_argument("--device-bvh", action="store_true")
+ap.add_argument("--sah", action="store_true", help="mesh BVHs cut by the binned surface-area heuristic (host build)")
+ap.add_argument("--leaf", type=int, default=0, help="most triangles in a leaf (0: builder default)")
 ap.add_argument("--assets", default=None, help="asset directory for the mixed / barrel scenes; 'synthetic' writes stand-ins to a temp dir")
 ap.add_argument("--stride", type=int, default=1, help="render only tiles 0, stride, 2*stride, ... (one GPU's share of a multi-GPU frame)")
 a = ap.parse_args()
@@ -43,7 +45,7 @@ if assets == "synthetic":
     assets = synth_assets.write_assets(tempfile.mkdtemp(prefix="rt_assets_"))
 t = time.time()
 scene = rt.HostScene(a.scene, a.width, a.height, a.size, a.lights, a.max_depth, asset_dir=assets, tight_bvh=not a.reference_bvh,
-                     device_bvh=a.device_bvh)
+                     device_bvh=a.device_bvh, sah_bvh=a.sah, leaf_threshold=a.leaf)
 print(f"scene {a.scene} size {a.size}: built in {time.time()-t:.2f}s, depth {scene.bvh_depth()}", flush=True)
 with rt.Context(0) as ctx:
     if a.waves:
