@@ -58,7 +58,7 @@ with rt.Context(0) as ctx:
         ctx.set_frames_in_flight(a.frames_in_flight)
     if a.lds_stack:
         ctx.set_lds_stack(a.lds_stack)
-    ctx.set_device_bvh(10, not a.reference_bvh)
+    ctx.set_device_bvh(a.leaf or 10, not a.reference_bvh)
     ctx.sync()
     t = time.time()
     ds = ctx.upload(scene)
