@@ -453,8 +453,9 @@ def main():
                     "in_order_ms_per_frame": f_alone[0], "in_order_Mrays_per_s": rays / f_alone_wall / 1e3,
                     "hit_key_agreement_with_exact_build": float(same_key.float().mean().item()) if world == 1 else None,
                     "radiance_within_tolerance_fraction": float(ok.float().mean().item()) if world == 1 else None,
-                    "note": "rt_set_arithmetic(FAST): min / max box test, shading contracted to fused multiply-adds, fp32 texture "
-                            "weights; everything that decides which primitive a ray hits keeps the exact arithmetic. Tolerance: hit keys "
+                    "note": "rt_set_arithmetic(FAST): shading contracted to fused multiply-adds, fp32 texture weights, the min / max box "
+                            "test for every ray (no second launch for rays along axis planes); everything else that decides which "
+                            "primitive a ray hits keeps the exact arithmetic. Tolerance: hit keys "
                             ">= 99.99 %, radiance 1e-4 relative or one 8-bit step (tests/test_gpu_fast_build.py holds it against the oracle)"}
         del exact_keys, fast_keys, exact_frame
 
@@ -505,7 +506,7 @@ def main():
         bvh_bytes = 32 * d.nodeCnt + 64 * d.shapeCnt + sum(32 * d.meshes[i].nodeCnt + 48 * d.meshes[i].triangleCnt for i in range(d.meshCnt))
         compulsory = bvh_bytes + HIT_RECORD_BYTES * traced // world
         wl_key = f"{args.scene}-{args.size}-{w}x{h}-l{args.lights}-d{args.max_depth}"
-        prof = profile_table(wl_key).get("traceKernel<false, false>", {}) if world == 1 else {}
+        prof = profile_table(wl_key).get("traceKernel<false, false, false>", {}) if world == 1 else {}
         prof_src = f"profiles/traffic.json <- profiles/{PROFILE_ROUND}: separate rocprofv3 --pmc passes of `bench.py --frames-in-flight 1`, NOT this run"
         ms_per_step = elapsed / args.steps * 1e3
         out = {
@@ -545,7 +546,7 @@ def main():
             "fast_build": fast,
             # The dominant kernel is the closest-hit trace of the primary rays.  What bounds it is fp32 vector work and the
             # latency of its dependent loads, not HBM: its working set (BVH + triangle records) stays in L2 / Infinity Cache.
-            "roofline": {"bound": "valu_fp32", "kernel": "traceKernel<false,false> (closest hit, primary rays)",
+            "roofline": {"bound": "valu_fp32", "kernel": "traceKernel<false,false,false> (closest hit, primary rays)",
                          "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
                          "algorithmic_flops_per_launch": closest_flops // world,
                          "launch_ms": closest_ms,
@@ -569,7 +570,7 @@ def main():
                          "instructions": {"valu_per_launch": prof.get("valu_insts_per_launch"),
                                           "valu_per_box_pair_or_triangle_phase": None,
                                           "source": prof_src if prof else None},
-                         "other_kernels": {"traceKernel<true,false> (shadow, any hit)": {"achieved": tflops(shadow_flops, shadow_ms), "unit": "TFLOP/s",
+                         "other_kernels": {"traceKernel<true,false,false> (shadow, any hit)": {"achieved": tflops(shadow_flops, shadow_ms), "unit": "TFLOP/s",
                                                                                          "algorithmic_flops_per_launch": shadow_flops // world,
                                                                                          "launch_ms": shadow_ms},
                                            "whole frame, by wall clock, frames in flight": {"achieved": tflops(closest_flops + shadow_flops, ms_per_step),

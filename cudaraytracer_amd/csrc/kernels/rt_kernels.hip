@@ -39,6 +39,8 @@
 // hit key, all of them on cube edges.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <algorithm>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -147,15 +149,16 @@ __device__ __forceinline__ void boxPairSlabs(const float4 n0, const float4 n1, c
     boxLiteral(n2, n3.x, n3.y, o, inv, nx, ny, nz, ok1, tMin1);
 }
 
-// The FAST build's form of the same test: near / far plane distance = the smaller / larger of the two plane distances
-// of an axis, and "largest entry <= smallest exit" for the reference's chain of comparisons.  It agrees with the
-// literal form whenever no plane distance is a NaN (finite ray origin, reciprocal direction finite and free of zeros)
-// and the boxes have min <= max: then (min - o) <= (max - o), a product with inv keeps or reverses that order, and the
+// The same test in min / max form: near / far plane distance = the smaller / larger of the two plane distances of an
+// axis, and "largest entry <= smallest exit" for the reference's chain of comparisons.  It agrees with the literal
+// form, bit for bit, whenever no plane distance is a NaN (finite ray origin, finite reciprocal direction) and the
+// boxes have min <= max: then (min - o) <= (max - o), a product with inv keeps or reverses that order, and the
 // smaller product is the reference's near-plane distance, formed by the same operations; the reference's comparisons
 // say "every entry <= every exit of ANOTHER axis", and entry <= exit of the SAME axis can only fail when a padded exit
 // distance is negative, where the box fails "exit > 0" in both forms.  A ray lying exactly in a box face (0 * inf) can
-// come out differently.  In the EXACT build this form bought nothing: with the literal form beside it for such rays
-// the kernel needs more registers than it saves instructions (measured: 1615 against 1625-1650 Mrays/s).
+// come out differently, which is why the EXACT build walks rays with an infinite reciprocal direction in a launch of
+// their own with the literal form (see traceKernel).  Both forms inside ONE kernel cost more registers than the
+// shorter form saves instructions (measured: 1 615 against 1 640 Mrays/s).
 __device__ __forceinline__ void boxPairMinMax(const float4 n0, const float4 n1, const float4 n2, const float4 n3, const V3 o, const V3 inv,
                                               bool& ok0, bool& ok1, float& tMin0, float& tMin1) {
     constexpr float kPad = 0x1.000006p+0f;
@@ -292,6 +295,8 @@ constexpr unsigned CUR_POP = 0xFFFFFFFFu, CUR_DONE = 0xFFFFFFFEu;
 constexpr unsigned TAG_TRI = 0x80000000u, TAG_SHAPE = 0xC0000000u, IDX_MASK = 0x3FFFFFFFu;
 constexpr unsigned STACK_MESH_EXIT = 0xFFFFFFFDu;  // stack marker: the mesh walk is over, restore the world-space ray
 constexpr int HIT_PENDING = -3;                    // hShape while the hit mesh is still being walked
+constexpr int HIT_DEFERRED = -4;                   // P.hit[].w of a ray left to the launch with the literal box test
+constexpr unsigned char VIS_DEFERRED = 2;          // P.vis[] of such a shadow ray
 
 #ifndef RT_POP_WHILE
 #define RT_POP_WHILE if  // one pop attempt per iteration of the main loop (`while` = pop until something is entered)
@@ -368,8 +373,18 @@ __device__ __forceinline__ bool triangleSolve(const float4 r0, const float4 r1, 
 // reference walk's even when a shadow ray stops early.  For that, this variant
 // also pushes far children that are already known to fail (marked by an
 // infinite entry distance).
-template <bool ANY, bool COUNT>
-__global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FrameParams P, const int level) {
+//
+// Box test (LIT).  The reference's slab test picks the near and the far plane of every axis by the sign of the ray's
+// direction and chains its comparisons so that a NaN (0 * inf: a ray that lies exactly in a box face) falls a
+// certain way.  Without a NaN the smaller / larger of the two plane distances IS the near / far distance, formed by
+// the same operations (boxPairMinMax), which saves a quarter of a node step's vector instructions.  A NaN needs an
+// infinite reciprocal direction, so in the EXACT build the LIT = false launch walks every ray whose reciprocal
+// direction is finite - in world space and in every mesh's object space it enters - and marks the others
+// (HIT_DEFERRED / VIS_DEFERRED, counted in CTL_DEFER_*); a second launch with the literal test (LIT = true, `rescue`)
+// walks the marked rays from the start and ends at once when there is none.  Counter launches use the literal test
+// for every ray.  The FAST build uses the min / max form for all rays and has no second launch.
+template <bool ANY, bool COUNT, bool LIT>
+__global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FrameParams P, const int level, const int rescue) {
     extern __shared__ uint2 s_dyn[];
     const int lane = threadIdx.x;
     // The top of each lane's traversal stack is a ring of ringN (a power of two) entries in LDS: entry e lives in
@@ -385,9 +400,17 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     // the world-space ray and the rest of the scene leaf wait here while a mesh is walked
     uint2* const gsave = gstk + (size_t)P.stackEntries * kWave;
 
+#ifdef RT_FAST
+    constexpr bool kDefer = false;
+#else
+    constexpr bool kDefer = !LIT;  // rays with an infinite reciprocal direction are left to the rescue launch
+#endif
+    if (rescue && P.ctl[(ANY ? CTL_DEFER_SHADOW : CTL_DEFER_CLOSEST)] == 0u) return;
     const unsigned total = ANY ? P.ctl[CTL_DIFFUSE_CNT] * (unsigned)P.lightCnt : P.ctl[CTL_LEVEL_COUNT + level];
     const unsigned first = ANY ? 0u : P.ctl[CTL_LEVEL_START + level];
-    unsigned* const queue = P.ctl + (ANY ? CTL_SHADOW_QUEUE : CTL_TRACE_QUEUE);
+    unsigned* const queue = P.ctl + (rescue ? (ANY ? CTL_SHADOW_RESCUE_QUEUE : CTL_TRACE_RESCUE_QUEUE) : (ANY ? CTL_SHADOW_QUEUE : CTL_TRACE_QUEUE));
+    // true if the min / max box test may differ from the literal one for a ray with this reciprocal direction
+    auto special = [](const V3 r) { return __builtin_isinf(r.x) || __builtin_isinf(r.y) || __builtin_isinf(r.z); };
     // With little work, only as many wavefronts take part as get P.waveChunks chunks each.  One chunk each spreads
     // the rays over the most wavefronts (shortest launch when nothing else runs); several make a wavefront refill
     // its lanes instead of running a single chunk dry, and leave slots free for the kernels of other frames in flight.
@@ -496,7 +519,9 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
             if (item >= 0 && cur == CUR_DONE) {
                 // ---- start this lane's new ray
                 bool valid = true;
-                if (ANY) {
+                if (rescue && (ANY ? P.vis[item] != VIS_DEFERRED : __float_as_int(P.hit[item].w) != HIT_DEFERRED)) {
+                    item = -1;  // walked by the first launch
+                } else if (ANY) {
                     const unsigned k = (unsigned)item / (unsigned)P.lightCnt;
                     const int li = (int)((unsigned)item - k * (unsigned)P.lightCnt);
                     shadowRay(P, k, li, o, d, tMax);
@@ -511,12 +536,16 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                         tMax = 3.402823466e+38f;
                     }
                 }
-                if (valid) {
+                if (item >= 0 && valid) inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                if (item < 0) {
+                    // nothing to walk
+                } else if (kDefer && valid && special(inv)) {
+                    hShape = HIT_DEFERRED;  // published as such below; cur stays CUR_DONE
+                } else if (valid) {
                     if (COUNT) {
                         cRays++;
                         rayTests = cNode + cTri;
                     }
-                    inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                     hShape = -1;
                     hTri = -1;
                     hu = hv = 0.0f;
@@ -687,11 +716,10 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
 #endif
                     float t0, t1;
                     bool g0, g1;
-#ifdef RT_FAST
-                    boxPairMinMax(L0, L1, L2, L3, o, inv, g0, g1, t0, t1);
-#else
-                    boxPairSlabs(L0, L1, L2, L3, o, inv, nx, ny, nz, g0, g1, t0, t1);
-#endif
+                    if (LIT)
+                        boxPairSlabs(L0, L1, L2, L3, o, inv, nx, ny, nz, g0, g1, t0, t1);
+                    else
+                        boxPairMinMax(L0, L1, L2, L3, o, inv, g0, g1, t0, t1);
                     const unsigned axis = RT_REF_AXIS(cur);
                     const bool single = axis == RT_REF_ROOT_AXIS;  // a root record: there is no sibling
                     // cudaTracer/Mesh.cuh:155-161: with a negative direction along the split axis the
@@ -759,6 +787,11 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     // cudaTracer/Mesh.cuh:137-138: root box test, or all triangles in order without a BVH
                     cur = useMeshBvhs ? m->rootRef : (TAG_TRI | m->recordBase);
                     end = m->recordBase + (unsigned)m->triangleCnt;
+                    if (kDefer && special(inv)) {
+                        // in this mesh's space the ray runs along an axis plane: the whole ray goes to the rescue launch
+                        hShape = HIT_DEFERRED;
+                        cur = CUR_DONE;
+                    }
                 }
             }
             STAMP(8);  // scene-leaf shapes
@@ -803,12 +836,14 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     atomicAdd(P.tileCost + tile, cNode + cTri - rayTests);
                 }
             }
+            const bool deferred = kDefer && hShape == HIT_DEFERRED;
+            if (deferred) atomicAdd(P.ctl + (ANY ? CTL_DEFER_SHADOW : CTL_DEFER_CLOSEST), 1u);
             if (ANY) {
-                P.vis[item] = hShape != -1 ? 0 : 1;
+                P.vis[item] = deferred ? VIS_DEFERRED : (hShape != -1 ? 0 : 1);
             } else {
                 int tri = hTri;
                 if (hShape >= 0 && shapes[hShape].kind == RT_SHAPE_MESH) tri -= (int)meshes[shapes[hShape].meshIdx].recordBase;
-                P.hit[item] = make_float4(tMax, hu, hv, __int_as_float(hShape >= 0 ? hShape : -1));
+                P.hit[item] = make_float4(tMax, hu, hv, __int_as_float(hShape >= 0 ? hShape : (deferred ? HIT_DEFERRED : -1)));
                 P.hitTri[item] = tri;
             }
             item = -1;
@@ -1239,42 +1274,73 @@ __global__ void advanceKernel(const FrameParams P, const int level) {
     P.ctl[CTL_TRACE_QUEUE] = 0;
     P.ctl[CTL_SHADOW_QUEUE] = 0;
     P.ctl[CTL_DIFFUSE_CNT] = 0;
+    P.ctl[CTL_TRACE_RESCUE_QUEUE] = 0;
+    P.ctl[CTL_SHADOW_RESCUE_QUEUE] = 0;
+    P.ctl[CTL_DEFER_CLOSEST] = 0;
+    P.ctl[CTL_DEFER_SHADOW] = 0;
 }
 
+// The box test of each launch kind: counter launches walk every ray with the literal test; the FAST build has only
+// the min / max form.
+#ifdef RT_FAST
+constexpr bool kCountLit = false;
+#else
+constexpr bool kCountLit = true;
+#endif
+
 // Resident wavefronts per CU of one trace-kernel variant (register and LDS limits), cached per LDS size.
-template <bool ANY, bool COUNT>
+template <bool ANY, bool COUNT, bool LIT>
 int wavesPerCu(size_t lds) {
     static size_t cachedLds = ~(size_t)0;
     static int cached = 0;
     if (lds != cachedLds) {
         int perCu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, traceKernel<ANY, COUNT>, kWave, lds) != hipSuccess || perCu < 1) perCu = 8;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, traceKernel<ANY, COUNT, LIT>, kWave, lds) != hipSuccess || perCu < 1) perCu = 8;
         cached = perCu > 32 ? 32 : perCu;
         cachedLds = lds;
-        if (getenv("RT_TRACE_DEBUG")) fprintf(stderr, "traceKernel<%d,%d>: %d resident wavefronts per CU with %zu B LDS\n", (int)ANY, (int)COUNT, cached, lds);
+        if (getenv("RT_TRACE_DEBUG"))
+            fprintf(stderr, "traceKernel<%d,%d,%d>: %d resident wavefronts per CU with %zu B LDS\n", (int)ANY, (int)COUNT, (int)LIT, cached, lds);
     }
     return cached;
 }
 
 // The grid is persistent: exactly as many wavefronts as stay resident for this variant, capped by
 // p.traceWaves (which also sizes the stack spill buffer).
+template <bool ANY, bool COUNT, bool LIT>
+void launchOne(const FrameParams& p, int level, int cuCount, hipStream_t s, int rescue) {
+    const size_t lds = traceLdsBytes(p.stackLds);
+    int waves = wavesPerCu<ANY, COUNT, LIT>(lds) * cuCount;
+    if (waves > p.traceWaves) waves = p.traceWaves;
+    // A rescue launch nearly always finds nothing to do: two wavefronts per CU keep it cheap to start and still walk a
+    // frame's worth of marked rays, if it ever comes to that, at a twelfth of the full rate.
+    if (rescue && waves > 2 * cuCount) waves = 2 * cuCount;
+    hipLaunchKernelGGL((traceKernel<ANY, COUNT, LIT>), dim3(waves), dim3(kWave), lds, s, p, level, rescue);
+}
 template <bool ANY, bool COUNT>
 void launchTrace(const FrameParams& p, int level, int cuCount, hipStream_t s) {
-    const size_t lds = traceLdsBytes(p.stackLds);
-    int waves = wavesPerCu<ANY, COUNT>(lds) * cuCount;
-    if (waves > p.traceWaves) waves = p.traceWaves;
-    hipLaunchKernelGGL((traceKernel<ANY, COUNT>), dim3(waves), dim3(kWave), lds, s, p, level);
+    if (COUNT) {
+        launchOne<ANY, true, kCountLit>(p, level, cuCount, s, 0);
+        return;
+    }
+    launchOne<ANY, false, false>(p, level, cuCount, s, 0);
+#ifndef RT_FAST
+    launchOne<ANY, false, true>(p, level, cuCount, s, 1);  // the rays the first launch left to the literal box test
+#endif
 }
 
 }  // namespace
 
 int RTK(rtk_trace_waves_per_cu)(int stackLds) {
     const size_t lds = traceLdsBytes(stackLds);
-    // the largest residency of the four variants: each launch takes its own, this one sizes the spill buffer
-    int w = wavesPerCu<false, false>(lds);
-    w = w > wavesPerCu<true, false>(lds) ? w : wavesPerCu<true, false>(lds);
-    w = w > wavesPerCu<false, true>(lds) ? w : wavesPerCu<false, true>(lds);
-    w = w > wavesPerCu<true, true>(lds) ? w : wavesPerCu<true, true>(lds);
+    // the largest residency of the variants: each launch takes its own, this one sizes the spill buffer
+    int w = wavesPerCu<false, false, false>(lds);
+    w = std::max(w, wavesPerCu<true, false, false>(lds));
+    w = std::max(w, wavesPerCu<false, true, kCountLit>(lds));
+    w = std::max(w, wavesPerCu<true, true, kCountLit>(lds));
+#ifndef RT_FAST
+    w = std::max(w, wavesPerCu<false, false, true>(lds));
+    w = std::max(w, wavesPerCu<true, false, true>(lds));
+#endif
     return w;
 }
 

@@ -143,6 +143,10 @@ enum {
     CTL_TRACE_QUEUE = 0,   // head of the closest-hit work queue of the current level
     CTL_SHADOW_QUEUE = 1,  // head of the shadow-ray work queue of the current level
     CTL_DIFFUSE_CNT = 2,   // diffuse hits of the current level
+    CTL_TRACE_RESCUE_QUEUE = 3,   // heads of the same two queues for the launches that walk the rays the first launches
+    CTL_SHADOW_RESCUE_QUEUE = 4,  // left to the literal box test
+    CTL_DEFER_CLOSEST = 5,        // rays of the current level left to those launches: closest hit,
+    CTL_DEFER_SHADOW = 6,         // shadow rays
     CTL_LEVEL_START = 8,   // [RT_MAX_DEPTH + 2] first node of each level
     CTL_LEVEL_COUNT = 40,  // [RT_MAX_DEPTH + 2] nodes of each level: while the level above is shaded, the slots its
                            // child rays ASKED for (may pass the arrays' end); once the level is opened, the nodes it holds

@@ -326,11 +326,12 @@ int rt_set_path_budget(rt_ctx* ctx, int nodesPerPixel);
  *   RT_ARITHMETIC_EXACT (default): every fp32 operation of the trace / shade path in the reference's operation
  *     order, no fused multiply-adds, IEEE division and square root: hit decisions and radiance are bit-identical to
  *     a host evaluation of the reference's formulas (cudaTracer/tracer.cu, Mesh.cuh, Sphere.cuh, BoundingBox.cuh).
- *   RT_ARITHMETIC_FAST: the same kernels compiled with contraction to fused multiply-adds, approximate division and
- *     square root, the box test folded into min / max form and fp32 texture weights.  Same algorithm, visiting order
+ *   RT_ARITHMETIC_FAST: the same kernels with the shading expressions contracted to fused multiply-adds, fp32
+ *     texture weights, and the min / max form of the box test for EVERY ray (EXACT gives rays that run along an axis
+ *     plane a launch of their own with the reference's literal comparison chain, whose outcome for a ray lying in a
+ *     box face - a NaN plane distance - the min / max form does not reproduce).  Same algorithm, visiting order
  *     and tie rule; results agree with EXACT within the parity tolerance (hit keys on >= 99.99 % of the pixels,
- *     radiance within 1e-4 relative or one 8-bit step), not bit for bit.  Rays grazing a triangle edge or lying in
- *     a box face may resolve differently.
+ *     radiance within 1e-4 relative or one 8-bit step), not bit for bit.
  * The reference has one build (nvcc's default contracts to FMA, cudaTracer/cudaTracer.vcxproj). */
 #define RT_ARITHMETIC_EXACT 0
 #define RT_ARITHMETIC_FAST 1

@@ -30,10 +30,12 @@ class Mesh:
     else a list of (bbmin, bbmax, offset, primCnt, axis) in the reference's depth-first order."""
 
     def __init__(self, triangles, material=DIFFUSE, ior=1.3, ks=0.0, spec_exp=25.0, diffuse=WHITE, specular=BLACK, normals=FLAT_NORMAL,
-                 nodes=None, mode=1):
+                 nodes=None, mode=1, transform_inverse=None, world_box=None):
         self.triangles, self.material, self.ior, self.ks, self.spec_exp = triangles, material, ior, ks, spec_exp
         self.maps = (diffuse, normals, specular)
         self.nodes, self.mode = nodes, mode
+        # row-major, row-vector convention (cudaTracer/Mat.cuh:127-149); with it, world_box = (min, max) of the shape
+        self.transform_inverse, self.world_box = transform_inverse, world_box
 
 
 def tri(p0, p1, p2, uv=((0, 0), (1, 0), (0, 1)), normal=(0, 0, -1)):
@@ -76,7 +78,10 @@ class Scene:
                 tex, buf = texture(px, m.mode)
                 setattr(dm, name, tex)
                 self.keep.append(buf)
-            dm.transformInverse[:] = np.eye(4, dtype=np.float32).ravel().tolist()
+            ti = np.eye(4, dtype=np.float32) if m.transform_inverse is None else np.asarray(m.transform_inverse, dtype=np.float32)
+            dm.transformInverse[:] = ti.ravel().tolist()
+            if m.world_box is not None:
+                b0, b1 = np.float32(m.world_box[0]), np.float32(m.world_box[1])
             s = self.shapes[mi]
             s.kind, s.meshIdx, s.tag = 1, mi, mi
             s.material.materialType, s.material.ior, s.material.Kd, s.material.Ks, s.material.specularExponent = m.material, m.ior, 0.8, m.ks, m.spec_exp
@@ -162,6 +167,10 @@ def probes():
     # sphere behind the ray origin: both roots negative
     P["sphere_behind"] = (Scene(1, 1, spheres=[((0, 0, 5), 1.0, DIFFUSE, 1.3, (0.4, 0.2, 0.1))], lights=LIGHT_AT_CAMERA, origin=(0, 0, 7)),
                           BG, (-1, -1, -1, -1))
+    # A ray that lies IN a face of a box misses that box (cudaTracer/BoundingBox.cuh:115-139): the plane distance is
+    # 0 * inf = NaN, which stays in tMin (near face: "tyMin > tMin" is false) and fails the final "tMin < ray.tMax".
+    # The triangle's left edge is on x = 0, the ray runs along x = 0: the reference never tests the triangle.
+    P["ray_in_box_face"] = (Scene(1, 1, [Mesh([tri((0, -3, 5), (0, 6, 5), (6, -3, 5))])], lights=LIGHT_AT_CAMERA), BG, (-1, -1, -1, -1))
     # mirror at normal incidence: the reflected ray leaves the scene, pixel = background * ((n - 1) / (n + 1))^2 = bg * 0.04
     # for n = 1.5 (cudaTracer/tracer.cu:67-89, 134-142)
     P["fresnel_normal_incidence"] = (Scene(1, 1, [Mesh([tri(*FRONT)], material=MIRROR, ior=1.5)], lights=LIGHT_AT_CAMERA, max_depth=1),
