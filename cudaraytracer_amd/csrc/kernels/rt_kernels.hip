@@ -405,9 +405,13 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
 #else
     constexpr bool kDefer = !LIT;  // rays with an infinite reciprocal direction are left to the rescue launch
 #endif
-    if (rescue && P.ctl[(ANY ? CTL_DEFER_SHADOW : CTL_DEFER_CLOSEST)] == 0u) return;
-    const unsigned total = ANY ? P.ctl[CTL_DIFFUSE_CNT] * (unsigned)P.lightCnt : P.ctl[CTL_LEVEL_COUNT + level];
-    const unsigned first = ANY ? 0u : P.ctl[CTL_LEVEL_START + level];
+    // the rays left to the rescue launch: listed behind the control words while the list lasts, marked in any case
+    const unsigned deferred = rescue ? P.ctl[(ANY ? CTL_DEFER_SHADOW : CTL_DEFER_CLOSEST)] : 0u;
+    if (rescue && deferred == 0u) return;
+    uint32_t* const deferList = P.ctl + CTL_WORDS + (ANY ? RT_DEFER_LIST : 0);
+    const bool fromList = rescue && deferred <= (unsigned)RT_DEFER_LIST;
+    const unsigned total = fromList ? deferred : (ANY ? P.ctl[CTL_DIFFUSE_CNT] * (unsigned)P.lightCnt : P.ctl[CTL_LEVEL_COUNT + level]);
+    const unsigned first = (ANY || fromList) ? 0u : P.ctl[CTL_LEVEL_START + level];
     unsigned* const queue = P.ctl + (rescue ? (ANY ? CTL_SHADOW_RESCUE_QUEUE : CTL_TRACE_RESCUE_QUEUE) : (ANY ? CTL_SHADOW_QUEUE : CTL_TRACE_QUEUE));
     // true if the min / max box test may differ from the literal one for a ray with this reciprocal direction
     auto special = [](const V3 r) { return __builtin_isinf(r.x) || __builtin_isinf(r.y) || __builtin_isinf(r.z); };
@@ -519,6 +523,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
             if (item >= 0 && cur == CUR_DONE) {
                 // ---- start this lane's new ray
                 bool valid = true;
+                if (fromList) item = (int)deferList[item];
                 if (rescue && (ANY ? P.vis[item] != VIS_DEFERRED : __float_as_int(P.hit[item].w) != HIT_DEFERRED)) {
                     item = -1;  // walked by the first launch
                 } else if (ANY) {
@@ -836,14 +841,17 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     atomicAdd(P.tileCost + tile, cNode + cTri - rayTests);
                 }
             }
-            const bool deferred = kDefer && hShape == HIT_DEFERRED;
-            if (deferred) atomicAdd(P.ctl + (ANY ? CTL_DEFER_SHADOW : CTL_DEFER_CLOSEST), 1u);
+            const bool leftOver = kDefer && hShape == HIT_DEFERRED;
+            if (leftOver) {
+                const unsigned at = atomicAdd(P.ctl + (ANY ? CTL_DEFER_SHADOW : CTL_DEFER_CLOSEST), 1u);
+                if (at < (unsigned)RT_DEFER_LIST) deferList[at] = (uint32_t)item;
+            }
             if (ANY) {
-                P.vis[item] = deferred ? VIS_DEFERRED : (hShape != -1 ? 0 : 1);
+                P.vis[item] = leftOver ? VIS_DEFERRED : (hShape != -1 ? 0 : 1);
             } else {
                 int tri = hTri;
                 if (hShape >= 0 && shapes[hShape].kind == RT_SHAPE_MESH) tri -= (int)meshes[shapes[hShape].meshIdx].recordBase;
-                P.hit[item] = make_float4(tMax, hu, hv, __int_as_float(hShape >= 0 ? hShape : (deferred ? HIT_DEFERRED : -1)));
+                P.hit[item] = make_float4(tMax, hu, hv, __int_as_float(hShape >= 0 ? hShape : (leftOver ? HIT_DEFERRED : -1)));
                 P.hitTri[item] = tri;
             }
             item = -1;

@@ -512,7 +512,7 @@ struct WsArray {
     const char* name;
 };
 std::vector<WsArray> workspaceArrays(size_t n, size_t sc, size_t lc) {
-    return {{&Workspace::ctl, CTL_WORDS * sizeof(uint32_t), "ctl"}, {&Workspace::hit, n * 16, "hit"},
+    return {{&Workspace::ctl, RT_CTL_BYTES, "ctl"}, {&Workspace::hit, n * 16, "hit"},
             {&Workspace::hitTri, n * 4, "hitTri"},                  {&Workspace::color, n * 16, "color"},
             {&Workspace::secRay, std::max<size_t>(sc * 32, 256), "secRay"}, {&Workspace::child, n * 4, "child"},
             {&Workspace::kr, n * 4, "kr"},                          {&Workspace::kind, n * 4, "kind"},

@@ -154,6 +154,11 @@ enum {
     CTL_OVERFLOW = 127,    // sticky: a child ray did not fit the node arrays
     CTL_WORDS = 128
 };
+// Behind the control words, in the same array: the work items left to the launches with the literal box test, closest
+// hit first, then shadow rays (RT_DEFER_LIST entries each; if a launch leaves more, the second launch looks through all
+// of the level's items for the marks instead).
+#define RT_DEFER_LIST 16384
+#define RT_CTL_BYTES ((CTL_WORDS + 2 * RT_DEFER_LIST) * sizeof(uint32_t))
 
 // Node kinds written by the shade kernel.
 enum { NODE_DONE = 0, NODE_MIRROR = 1, NODE_GLASS = 2 };

@@ -47,6 +47,21 @@ def test_surface_area_tree_frame_matches_oracle(gpu_ctx, oracle, name, w, h, siz
     assert cnt == ref_cnt, (cnt, ref_cnt)
 
 
+@pytest.mark.parametrize("h", [300, 20000])
+def test_frame_of_rays_along_an_axis_plane(gpu_ctx, oracle, h):
+    """A frame one pixel wide: every primary ray has d.x == 0, so the whole frame is walked by the launch with the
+    literal box test - from its list of left-over rays (300 rays), or, when the list is too short (20 000 rays), by
+    looking through all of the level's items."""
+    scene = rt.HostScene("soup", 1, h, 20000, 2, 0, tight_bvh=True)
+    ref_rgba, ref_keys, ref_cnt = oracle.render(scene.desc, scene.opts, scene.camera, 1, h, threads=8, shadow_any_hit=True)
+    rgba, keys, cnt = gpu_ctx.render_frame(scene, want_keys=True, want_counters=True)
+    assert (ref_keys[..., 0] >= 0).sum() > h // 20  # the strip does see triangles
+    assert_parity(rgba, keys, ref_rgba, ref_keys)
+    assert cnt == ref_cnt
+    rgba2, keys2, _ = gpu_ctx.render_frame(scene, want_keys=True)
+    assert np.array_equal(keys, keys2) and np.array_equal(rgba, rgba2, equal_nan=True)
+
+
 # ---- OBJ + PNG assets: reader, decoder, tangents, CLAMP and WRAP texturing of 1024x1024 maps -----------------
 @pytest.mark.parametrize("name,w,h,lights,depth", [("barrel", 200, 150, 4, 2), ("mixed", 160, 120, 10, 3), ("barrel", 97, 61, 1, 0)])
 def test_asset_scenes_match_oracle(gpu_ctx, oracle, synthetic_assets, name, w, h, lights, depth):
