@@ -160,25 +160,21 @@ __device__ __forceinline__ void boxPairSlabs(const float4 n0, const float4 n1, c
 // their own with the literal form (see traceKernel).  Both forms inside ONE kernel cost more registers than the
 // shorter form saves instructions (measured: 1 615 against 1 640 Mrays/s).
 __device__ __forceinline__ void boxPairMinMax(const float4 n0, const float4 n1, const float4 n2, const float4 n3, const V3 o, const V3 inv,
-                                              bool& ok0, bool& ok1, float& tMin0, float& tMin1) {
+                                              float& tMin0, float& tMax0, float& tMin1, float& tMax1) {
     constexpr float kPad = 0x1.000006p+0f;
     {
         const float ax = (n0.x - o.x) * inv.x, bx = (n0.w - o.x) * inv.x;
         const float ay = (n0.y - o.y) * inv.y, by = (n1.x - o.y) * inv.y;
         const float az = (n0.z - o.z) * inv.z, bz = (n1.y - o.z) * inv.z;
-        const float tMin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-        const float tMax = fminf(fminf(fmaxf(ax, bx) * kPad, fmaxf(ay, by) * kPad), fmaxf(az, bz));
-        tMin0 = tMin;
-        ok0 = tMin <= tMax && tMax > 0.0f;
+        tMin0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        tMax0 = fminf(fminf(fmaxf(ax, bx) * kPad, fmaxf(ay, by) * kPad), fmaxf(az, bz));
     }
     {
         const float ax = (n2.x - o.x) * inv.x, bx = (n2.w - o.x) * inv.x;
         const float ay = (n2.y - o.y) * inv.y, by = (n3.x - o.y) * inv.y;
         const float az = (n2.z - o.z) * inv.z, bz = (n3.y - o.z) * inv.z;
-        const float tMin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-        const float tMax = fminf(fminf(fmaxf(ax, bx) * kPad, fmaxf(ay, by) * kPad), fmaxf(az, bz));
-        tMin1 = tMin;
-        ok1 = tMin <= tMax && tMax > 0.0f;
+        tMin1 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+        tMax1 = fminf(fminf(fmaxf(ax, bx) * kPad, fmaxf(ay, by) * kPad), fmaxf(az, bz));
     }
 }
 // cudaTracer/Sphere.cuh:9-54
@@ -719,25 +715,34 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                         asm volatile("" ::"s"(s0));
                     }
 #endif
+                    // Lane predicates live in scalar mask registers: every mask below is the ballot of ONE comparison (a
+                    // vector compare that writes a scalar register pair) and all the logic on them is scalar arithmetic.
+                    const auto B = [](bool c) { return __builtin_amdgcn_ballot_w64(c); };
                     float t0, t1;
-                    bool g0, g1;
-                    if (LIT)
+                    unsigned long long mH0, mH1;  // child 0 / 1 is hit within the ray's reach
+                    if (LIT) {
+                        bool g0, g1;
                         boxPairSlabs(L0, L1, L2, L3, o, inv, nx, ny, nz, g0, g1, t0, t1);
-                    else
-                        boxPairMinMax(L0, L1, L2, L3, o, inv, g0, g1, t0, t1);
+                        mH0 = __ballot(g0 && t0 < tMax);
+                        mH1 = __ballot(g1 && t1 < tMax);
+                    } else {
+                        float f0, f1;
+                        boxPairMinMax(L0, L1, L2, L3, o, inv, t0, f0, t1, f1);
+                        mH0 = B(t0 <= f0) & B(f0 > 0.0f) & B(t0 < tMax);
+                        mH1 = B(t1 <= f1) & B(f1 > 0.0f) & B(t1 < tMax);
+                    }
                     const unsigned axis = RT_REF_AXIS(cur);
-                    const bool single = axis == RT_REF_ROOT_AXIS;  // a root record: there is no sibling
                     // cudaTracer/Mesh.cuh:155-161: with a negative direction along the split axis the
-                    // second child is nearer; the other one waits on the stack.  (Lane predicates are combined
-                    // with and / or rather than selected, which keeps them in scalar mask registers.)
-                    const bool negAxis = (axis == 0 && nx) || (axis == 1 && ny) || (axis == 2 && nz);
+                    // second child is nearer; the other one waits on the stack.  A root record has no sibling.
+                    const unsigned long long mNeg = (B(axis == 0u) & B(inv.x < 0.0f)) | (B(axis == 1u) & B(inv.y < 0.0f)) | (B(axis == 2u) & B(inv.z < 0.0f));
+                    const unsigned long long mSingle = B(axis == (unsigned)RT_REF_ROOT_AXIS);
+                    const bool single = __builtin_amdgcn_inverse_ballot_w64(mSingle);
+                    const bool negAxis = __builtin_amdgcn_inverse_ballot_w64(mNeg);
                     const unsigned nearRef = __float_as_uint(negAxis ? L3.z : L1.z);
                     const unsigned farRef = __float_as_uint(negAxis ? L1.z : L3.z);
-                    // near / far outcome = the two boxes' outcomes swapped where negAxis holds: done on the wavefront's
-                    // lane masks (scalar registers), which costs no vector instruction
-                    const unsigned long long mNeg = __ballot(negAxis), mH0 = __ballot(g0 && t0 < tMax), mH1 = __ballot(g1 && t1 < tMax);
+                    // near / far outcome = the two boxes' outcomes swapped where negAxis holds
                     const bool nearHit = __builtin_amdgcn_inverse_ballot_w64((mNeg & mH1) | (~mNeg & mH0));
-                    const bool farHit = __builtin_amdgcn_inverse_ballot_w64(((mNeg & mH0) | (~mNeg & mH1)) & ~__ballot(single));
+                    const bool farHit = __builtin_amdgcn_inverse_ballot_w64(((mNeg & mH0) | (~mNeg & mH1)) & ~mSingle);
                     const float farT = negAxis ? t0 : t1;
                     const bool doPush = COUNT ? !single : farHit;
                     // the entry is written in any case (above the top of the stack it is harmless; with a full
