@@ -377,8 +377,8 @@ __device__ __forceinline__ bool triangleSolve(const float4 r0, const float4 r1, 
 // infinite reciprocal direction, so in the EXACT build the LIT = false launch walks every ray whose reciprocal
 // direction is finite - in world space and in every mesh's object space it enters - and marks the others
 // (HIT_DEFERRED / VIS_DEFERRED, counted in CTL_DEFER_*); a second launch with the literal test (LIT = true, `rescue`)
-// walks the marked rays from the start and ends at once when there is none.  Counter launches use the literal test
-// for every ray.  The FAST build uses the min / max form for all rays and has no second launch.
+// walks the marked rays from the start and ends at once when there is none.  Counter launches, small frames and
+// reflection levels use the literal test for every ray, in one launch (launchTrace).  The FAST build uses the min / max form for all rays and has no second launch.
 template <bool ANY, bool COUNT, bool LIT>
 __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FrameParams P, const int level, const int rescue) {
     extern __shared__ uint2 s_dyn[];
@@ -1335,9 +1335,18 @@ void launchTrace(const FrameParams& p, int level, int cuCount, hipStream_t s) {
         launchOne<ANY, true, kCountLit>(p, level, cuCount, s, 0);
         return;
     }
+#ifdef RT_FAST
     launchOne<ANY, false, false>(p, level, cuCount, s, 0);
-#ifndef RT_FAST
-    launchOne<ANY, false, true>(p, level, cuCount, s, 1);  // the rays the first launch left to the literal box test
+#else
+    // Two launches pay where the rays are: the primary rays of a large frame and their shadow rays.  A kernel
+    // boundary costs 15-25 us of an in-order frame, more than the shorter box test saves on a small frame or on the
+    // few rays of a reflection level: those are walked by one launch with the literal test.
+    if (level == 0 && p.slots >= p.splitSlots) {
+        launchOne<ANY, false, false>(p, level, cuCount, s, 0);
+        launchOne<ANY, false, true>(p, level, cuCount, s, 1);  // the rays the first launch left to the literal box test
+    } else {
+        launchOne<ANY, false, true>(p, level, cuCount, s, 0);
+    }
 #endif
 }
 

@@ -83,6 +83,7 @@ struct rt_ctx {
     int framesInFlight = 1;
     unsigned long long frameCounter = 0;  // frames issued so far
     int pathBudget = 3;  // node arrays hold pathBudget x pixels when the scene has mirror / glass materials
+    int splitSlots = 1 << 18;             // rt_set_box_test_split
     int ldsStack = RT_LDS_STACK_DEFAULT;  // traversal stack entries kept in LDS (older ones move to global memory)
     int maxWavesPerCu = 0;                // 0 = as many as are resident
     uint32_t sampleSeed = 1234;
@@ -773,6 +774,13 @@ int rt_set_lds_stack(rt_ctx* ctx, int entries) {
     return RT_OK;
 }
 
+int rt_set_box_test_split(rt_ctx* ctx, int minRays) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (minRays < 0) return fail(ctx, RT_ERR_INVALID, "the threshold is a number of rays");
+    ctx->splitSlots = minRays;
+    return RT_OK;
+}
+
 int rt_set_workspace_guards(rt_ctx* ctx, size_t bytes) {
     if (!ctx) return RT_ERR_INVALID;
     if (bytes > (1u << 20) || bytes % 256 != 0) return fail(ctx, RT_ERR_INVALID, "guard size must be a multiple of 256 bytes, at most 1 MiB");
@@ -1146,6 +1154,7 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
     // launches with more than 6000 chunks (a half or a quarter of a 1080p frame) do 2-5 % better with 6 when frames overlap
     p.waveChunks = 4;
     p.waveChunksLarge = ctx->framesInFlight > 1 ? 6 : 4;  // alone on the machine, a launch is shortest with the most wavefronts
+    p.splitSlots = ctx->splitSlots;
     p.tileFirst = tileFirst;
     p.tileStride = tileStride;
     p.tileCnt = (int)myTiles;

@@ -417,6 +417,15 @@ int rt_set_tile_cost_buffer(rt_ctx* ctx, uint32_t* devCost);
  * depend on it. */
 int rt_set_lds_stack(rt_ctx* ctx, int entries);
 
+/* Box test of the EXACT build.  The reference's slab test (cudaTracer/BoundingBox.cuh:115-139) equals its min / max
+ * form - fewer instructions - bit for bit unless a plane distance is a NaN, which takes an infinite reciprocal
+ * direction.  The trace of a frame's primary rays, and of their shadow rays, therefore runs as two launches when the
+ * call renders at least `minRays` primary rays (default 262144; INT_MAX = never): the first walks the rays with a
+ * finite reciprocal direction with the min / max form, the second the others with the literal form (it ends at once
+ * when there are none).  Smaller frames and reflection levels use the literal form in one launch: a kernel boundary
+ * costs more than they would save.  Results do not depend on it, bit for bit.  No counterpart in the reference. */
+int rt_set_box_test_split(rt_ctx* ctx, int minRays);
+
 /* Frames in flight (1..16, default 1).  With 1, rt_render enqueues the frame on the
  * context's stream, in order, as the reference's cudamain does on the default
  * stream (cudaTracer/Main.cu:92-119).  With more, consecutive rt_render calls run

@@ -32,6 +32,10 @@ def gpu_ctx():
     import cudaraytracer_amd as rt
 
     ctx = rt.Context(0)
+    # The shared context walks even the small test frames the way large frames are walked (two launches per trace:
+    # min / max box test, then the literal one for rays along axis planes); contexts that tests create themselves keep
+    # the default, under which small frames take the literal test in one launch.
+    ctx.set_box_test_split(0)
     yield ctx
     ctx.close()
 

@@ -22,19 +22,29 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("one_launch", [False, True])
 @pytest.mark.parametrize("name,w,h,size,lights,depth,tight", CASES)
-def test_frame_matches_oracle(gpu_ctx, oracle, name, w, h, size, lights, depth, tight):
+def test_frame_matches_oracle(gpu_ctx, oracle, name, w, h, size, lights, depth, tight, one_launch):
     scene = rt.HostScene(name, w, h, size, lights, depth, tight_bvh=tight)
     ref_rgba, ref_keys, ref_cnt = oracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=8, shadow_any_hit=True)
-    rgba, keys, cnt = gpu_ctx.render_frame(scene, want_keys=True, want_counters=True)
+    gpu_ctx.set_box_test_split(2**31 - 1 if one_launch else 0)  # literal box test in one launch / two launches
+    try:
+        rgba, keys, cnt, rgba2, keys2 = _frames(gpu_ctx, scene)
+    finally:
+        gpu_ctx.set_box_test_split(0)
     r = assert_parity(rgba, keys, ref_rgba, ref_keys)
     print(name, r)
     # the counter build walks exactly the oracle's traversal: integer-exact test counts
     assert cnt == ref_cnt, (cnt, ref_cnt)
     # and the plain build renders the same frame as the counter build
-    rgba2, keys2, _ = gpu_ctx.render_frame(scene, want_keys=True)
     assert np.array_equal(keys, keys2)
     assert np.array_equal(rgba, rgba2, equal_nan=True)
+
+
+def _frames(ctx, scene):
+    rgba, keys, cnt = ctx.render_frame(scene, want_keys=True, want_counters=True)
+    rgba2, keys2, _ = ctx.render_frame(scene, want_keys=True)
+    return rgba, keys, cnt, rgba2, keys2
 
 
 @pytest.mark.parametrize("name,w,h,size,lights,depth", [("soup", 192, 108, 200000, 1, 0), ("heightfield", 160, 96, 20000, 2, 0), ("mixed", 160, 120, 0, 4, 3)])
@@ -175,7 +185,7 @@ def test_knobs_do_not_change_the_frame(gpu_ctx):
     try:
         base = gpu_ctx.render_frame(scene, dscene, want_keys=True, want_counters=True)
         for setter, values, restore in ((gpu_ctx.set_lds_stack, (1, 3, 8, 64), 8), (gpu_ctx.set_frames_in_flight, (2, 4), 1), (gpu_ctx.set_tile_order, (0, 1), 1),
-                                        (gpu_ctx.set_trace_waves, (1, 4, 32), 0)):
+                                        (gpu_ctx.set_trace_waves, (1, 4, 32), 0), (gpu_ctx.set_box_test_split, (2**31 - 1, 20000), 0)):
             try:
                 for v in values:
                     setter(v)
@@ -183,6 +193,8 @@ def test_knobs_do_not_change_the_frame(gpu_ctx):
                     assert np.array_equal(got[1], base[1]), (setter.__name__, v)
                     assert np.array_equal(got[0], base[0], equal_nan=True), (setter.__name__, v)
                     assert got[2] == base[2], (setter.__name__, v)
+                    plain = gpu_ctx.render_frame(scene, dscene, want_keys=True)  # the build without counters
+                    assert np.array_equal(plain[1], base[1]) and np.array_equal(plain[0], base[0], equal_nan=True), (setter.__name__, v)
             finally:
                 setter(restore)
     finally:
