@@ -1027,8 +1027,10 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams P, const in
     const V3 bg = mk(P.opts.backgroundColor);
     const DevShape* shapes = reinterpret_cast<const DevShape*>(P.blob + P.offShapes);
     unsigned cMesh = 0, cSphere = 0;
+    // per round: diffuse hits and child rays of the block's four wavefronts, and the first slot of each kind
+    __shared__ unsigned s_count[4], s_want[4], s_base, s_childBase;
     const unsigned stride = gridDim.x * blockDim.x;
-    // every lane of a wave runs the same number of iterations (the ballots below need that)
+    // every thread of a block runs the same number of iterations (the ballots and barriers below need that)
     const unsigned rounds = (count + stride - 1) / stride;
     for (unsigned r = 0; r < rounds; ++r) {
         const unsigned idx = r * stride + blockIdx.x * blockDim.x + threadIdx.x;
@@ -1094,29 +1096,14 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams P, const in
                 }
             }
         }
-        // ---- diffuse hits: compact into the level's shading-context list
-        const unsigned long long dmask = __ballot(diffuse);
-        if (dmask != 0ull) {
-            unsigned base = 0;
-            if (laneRank(dmask) == 0 && diffuse) base = atomicAdd(P.ctl + CTL_DIFFUSE_CNT, (unsigned)__popcll(dmask));
-            base = __shfl(base, __ffsll((long long)dmask) - 1, kWave);
-            if (diffuse) {
-                const unsigned k = base + laneRank(dmask);
-                float4* c = P.ctx + 4 * (size_t)k;
-                c[0] = make_float4(hitPoint.x, hitPoint.y, hitPoint.z, n.x);
-                c[1] = make_float4(n.y, n.z, rd.x, rd.y);
-                c[2] = make_float4(rd.z, diffuseColor.x, diffuseColor.y, diffuseColor.z);
-                c[3] = make_float4(specMask, specExp, 0.0f, 0.0f);
-                P.ctxNode[k] = node;
-                P.kind[node] = NODE_DONE;
-            }
-        }
-        // ---- mirror / glass hits
+        // ---- mirror / glass hits: directions and Fresnel term; at the last level the children are the background
+        V3 reflDir = mk(0, 0, 0);
+        float kr = 0.0f;
         if (want > 0) {
             // cudaTracer/tracer.cu:117-142.  Glass reflects the NORMAL about the view direction
             // (operands swapped with respect to the mirror case), as the reference does.
-            const V3 reflDir = normalized(materialType == RT_MAT_REFLECTION ? reflect(rd, n) : reflect(n, rd));
-            const float kr = fresnel(rd, n, ior);
+            reflDir = normalized(materialType == RT_MAT_REFLECTION ? reflect(rd, n) : reflect(n, rd));
+            kr = fresnel(rd, n, ior);
             if (level >= P.opts.maxDepth) {
                 // children would be deeper than maxDepth: each returns the background
                 const V3 c = (want == 1) ? muls(bg, kr) : add(muls(bg, kr), muls(bg, 1.0f - kr));
@@ -1127,35 +1114,64 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams P, const in
                 P.kr[node] = kr;
                 P.kind[node] = want == 1 ? NODE_MIRROR : NODE_GLASS;
             }
-            if (want > 0) {
-                // exclusive prefix of `want` over the wave via two ballots (want is 1 or 2)
-                const unsigned long long m1 = __ballot(want >= 1), m2 = __ballot(want == 2);
-                const unsigned totalWant = (unsigned)__popcll(m1) + (unsigned)__popcll(m2);
-                unsigned base = 0;
-                if (laneRank(m1) == 0) base = atomicAdd(P.ctl + CTL_LEVEL_COUNT + level + 1, totalWant);
-                base = __shfl(base, __ffsll((long long)m1) - 1, kWave);
-                const unsigned mine = nextStart + base + laneRank(m1) + laneRank(m2);
-                if (mine + (unsigned)want > (unsigned)P.nodeCap) {
-                    // no room: report, and fall back to the background so that nothing is read out of bounds.
-                    // Requests are handed out in increasing order, so every later one fails too and at most one
-                    // request straddles the arrays' end: the slots below it are the level's last nodes.
-                    atomicOr(P.ctl + CTL_OVERFLOW, 1u);
-                    if (mine < (unsigned)P.nodeCap) P.ctl[CTL_LEVEL_FIT + level + 1] = (mine - nextStart) + 1u;
-                    const V3 c = (want == 1) ? muls(bg, kr) : add(muls(bg, kr), muls(bg, 1.0f - kr));
-                    P.color[node] = make_float4(c.x, c.y, c.z, 0.0f);
-                    P.kind[node] = NODE_DONE;
-                } else {
-                    P.child[node] = (int)mine;
-                    float4* r = P.secRay + 2 * (size_t)(mine - (unsigned)P.slots);
-                    const V3 reflOrig = invBiasedOrigin(reflDir, hitPoint, n, P.opts.shadowBias);
-                    r[0] = make_float4(reflOrig.x, reflOrig.y, reflOrig.z, 0.0f);
-                    r[1] = make_float4(reflDir.x, reflDir.y, reflDir.z, 0.0f);
-                    if (want == 2) {
-                        const V3 refrDir = normalized(refract(rd, n, ior));
-                        const V3 refrOrig = invBiasedOrigin(refrDir, hitPoint, n, P.opts.shadowBias);
-                        r[2] = make_float4(refrOrig.x, refrOrig.y, refrOrig.z, 0.0f);
-                        r[3] = make_float4(refrDir.x, refrDir.y, refrDir.z, 0.0f);
-                    }
+        }
+        // ---- slots in the level's shading-context list (diffuse hits) and in the next level (child rays): ballot
+        // compaction per wavefront, then ONE atomic of each kind per block and round - tens of thousands of atomics
+        // on one address take longer than everything else this kernel does
+        const unsigned long long dmask = __ballot(diffuse);
+        const unsigned long long m1 = __ballot(want >= 1), m2 = __ballot(want == 2);  // want is 0, 1 or 2
+        const unsigned wave = threadIdx.x >> 6;
+        if ((threadIdx.x & 63u) == 0u) {
+            s_count[wave] = (unsigned)__popcll(dmask);
+            s_want[wave] = (unsigned)__popcll(m1) + (unsigned)__popcll(m2);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned hits = s_count[0] + s_count[1] + s_count[2] + s_count[3];
+            const unsigned children = s_want[0] + s_want[1] + s_want[2] + s_want[3];
+            s_base = hits ? atomicAdd(P.ctl + CTL_DIFFUSE_CNT, hits) : 0u;
+            s_childBase = children ? atomicAdd(P.ctl + CTL_LEVEL_COUNT + level + 1, children) : 0u;
+        }
+        __syncthreads();
+        unsigned base = s_base, childBase = s_childBase;
+        for (unsigned w = 0; w < wave; ++w) {
+            base += s_count[w];
+            childBase += s_want[w];
+        }
+        __syncthreads();  // the next round overwrites the counts
+        if (diffuse) {
+            const unsigned k = base + laneRank(dmask);
+            float4* c = P.ctx + 4 * (size_t)k;
+            c[0] = make_float4(hitPoint.x, hitPoint.y, hitPoint.z, n.x);
+            c[1] = make_float4(n.y, n.z, rd.x, rd.y);
+            c[2] = make_float4(rd.z, diffuseColor.x, diffuseColor.y, diffuseColor.z);
+            c[3] = make_float4(specMask, specExp, 0.0f, 0.0f);
+            P.ctxNode[k] = node;
+            P.kind[node] = NODE_DONE;
+        }
+        if (want > 0) {
+            // exclusive prefix of `want` over the wave from the two ballots
+            const unsigned mine = nextStart + childBase + laneRank(m1) + laneRank(m2);
+            if (mine + (unsigned)want > (unsigned)P.nodeCap) {
+                // no room: report, and fall back to the background so that nothing is read out of bounds.
+                // Requests are handed out in increasing order, so every later one fails too and at most one
+                // request straddles the arrays' end: the slots below it are the level's last nodes.
+                atomicOr(P.ctl + CTL_OVERFLOW, 1u);
+                if (mine < (unsigned)P.nodeCap) P.ctl[CTL_LEVEL_FIT + level + 1] = (mine - nextStart) + 1u;
+                const V3 c = (want == 1) ? muls(bg, kr) : add(muls(bg, kr), muls(bg, 1.0f - kr));
+                P.color[node] = make_float4(c.x, c.y, c.z, 0.0f);
+                P.kind[node] = NODE_DONE;
+            } else {
+                P.child[node] = (int)mine;
+                float4* r = P.secRay + 2 * (size_t)(mine - (unsigned)P.slots);
+                const V3 reflOrig = invBiasedOrigin(reflDir, hitPoint, n, P.opts.shadowBias);
+                r[0] = make_float4(reflOrig.x, reflOrig.y, reflOrig.z, 0.0f);
+                r[1] = make_float4(reflDir.x, reflDir.y, reflDir.z, 0.0f);
+                if (want == 2) {
+                    const V3 refrDir = normalized(refract(rd, n, ior));
+                    const V3 refrOrig = invBiasedOrigin(refrDir, hitPoint, n, P.opts.shadowBias);
+                    r[2] = make_float4(refrOrig.x, refrOrig.y, refrOrig.z, 0.0f);
+                    r[3] = make_float4(refrDir.x, refrDir.y, refrDir.z, 0.0f);
                 }
             }
         }
