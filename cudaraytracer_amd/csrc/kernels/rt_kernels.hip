@@ -404,11 +404,12 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     // the rays left to the rescue launch: listed behind the control words while the list lasts, marked in any case
     const unsigned deferred = rescue ? P.ctl[(ANY ? CTL_DEFER_SHADOW : CTL_DEFER_CLOSEST)] : 0u;
     if (rescue && deferred == 0u) return;
-    uint32_t* const deferList = P.ctl + CTL_WORDS + (ANY ? RT_DEFER_LIST : 0);
+    uint32_t* const deferList = P.ctl + RT_DEFER_WORD(ANY);
     const bool fromList = rescue && deferred <= (unsigned)RT_DEFER_LIST;
     const unsigned total = fromList ? deferred : (ANY ? P.ctl[CTL_DIFFUSE_CNT] * (unsigned)P.lightCnt : P.ctl[CTL_LEVEL_COUNT + level]);
     const unsigned first = (ANY || fromList) ? 0u : P.ctl[CTL_LEVEL_START + level];
-    unsigned* const queue = P.ctl + (rescue ? (ANY ? CTL_SHADOW_RESCUE_QUEUE : CTL_TRACE_RESCUE_QUEUE) : (ANY ? CTL_SHADOW_QUEUE : CTL_TRACE_QUEUE));
+    unsigned* const queues = P.ctl + RT_QUEUE_WORD((rescue ? 2 : 0) + (ANY ? 1 : 0), 0);
+    const unsigned chunks = (total + kChunk - 1) / kChunk;
     // true if the min / max box test may differ from the literal one for a ray with this reciprocal direction
     auto special = [](const V3 r) { return __builtin_isinf(r.x) || __builtin_isinf(r.y) || __builtin_isinf(r.z); };
     // With little work, only as many wavefronts take part as get P.waveChunks chunks each.  One chunk each spreads
@@ -434,6 +435,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
 
     // wave-uniform queue state
     unsigned chunkNext = 0, chunkEnd = 0;
+    unsigned dryQueues = 0;  // counters this wavefront has found dry, starting with its own (blockIdx % RT_QUEUES)
     bool exhausted = false;
 
     // per-lane ray state
@@ -501,15 +503,26 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
             unsigned given = 0;
             while (given < want) {
                 if (chunkNext == chunkEnd) {
-                    unsigned b = 0;
-                    if (lane == 0) b = atomicAdd(queue, kChunk);
-                    b = __builtin_amdgcn_readfirstlane(b);
-                    if (b >= total) {
+                    unsigned c = chunks;
+                    while (dryQueues < (unsigned)RT_QUEUES) {
+                        const unsigned q = (blockIdx.x + dryQueues) % (unsigned)RT_QUEUES;
+                        const unsigned held = (chunks + RT_QUEUES - 1 - q) / RT_QUEUES;  // chunks q, q + RT_QUEUES, ...
+                        unsigned i = 0;
+                        if (lane == 0) i = atomicAdd(queues + q * RT_QUEUE_STRIDE, 1u);
+                        i = __builtin_amdgcn_readfirstlane(i);
+                        // (i cannot wrap: a counter is asked at most once per chunk it holds plus once per wavefront)
+                        if (i < held) {
+                            c = q + i * RT_QUEUES;
+                            break;
+                        }
+                        ++dryQueues;
+                    }
+                    if (c >= chunks) {
                         exhausted = true;
                         break;
                     }
-                    chunkNext = b;
-                    chunkEnd = (total - b < kChunk) ? total : b + kChunk;
+                    chunkNext = c * kChunk;
+                    chunkEnd = (total - chunkNext < kChunk) ? total : chunkNext + kChunk;
                 }
                 const unsigned take = (want - given < chunkEnd - chunkNext) ? want - given : chunkEnd - chunkNext;
                 if (item < 0 && rank >= given && rank < given + take) item = (int)(first + chunkNext + (rank - given));
@@ -1300,11 +1313,9 @@ __global__ void advanceKernel(const FrameParams P, const int level) {
         P.ctl[CTL_LEVEL_START + level] = start;
         P.ctl[CTL_LEVEL_COUNT + level] = count;
     }
-    P.ctl[CTL_TRACE_QUEUE] = 0;
-    P.ctl[CTL_SHADOW_QUEUE] = 0;
+    for (int kind = 0; kind < 4; ++kind)
+        for (int q = 0; q < RT_QUEUES; ++q) P.ctl[RT_QUEUE_WORD(kind, q)] = 0;
     P.ctl[CTL_DIFFUSE_CNT] = 0;
-    P.ctl[CTL_TRACE_RESCUE_QUEUE] = 0;
-    P.ctl[CTL_SHADOW_RESCUE_QUEUE] = 0;
     P.ctl[CTL_DEFER_CLOSEST] = 0;
     P.ctl[CTL_DEFER_SHADOW] = 0;
 }

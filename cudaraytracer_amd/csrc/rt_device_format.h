@@ -140,13 +140,9 @@ static_assert(sizeof(TriRecord) == 48, "TriRecord size");
 // Control block (uint32 words in device memory).  Every word except CTL_OVERFLOW is cleared when a frame opens
 // its first level; CTL_OVERFLOW stays set until rt_sync has reported it.
 enum {
-    CTL_TRACE_QUEUE = 0,   // head of the closest-hit work queue of the current level
-    CTL_SHADOW_QUEUE = 1,  // head of the shadow-ray work queue of the current level
     CTL_DIFFUSE_CNT = 2,   // diffuse hits of the current level
-    CTL_TRACE_RESCUE_QUEUE = 3,   // heads of the same two queues for the launches that walk the rays the first launches
-    CTL_SHADOW_RESCUE_QUEUE = 4,  // left to the literal box test
-    CTL_DEFER_CLOSEST = 5,        // rays of the current level left to those launches: closest hit,
-    CTL_DEFER_SHADOW = 6,         // shadow rays
+    CTL_DEFER_CLOSEST = 5,  // rays of the current level left to the launches with the literal box test: closest hit,
+    CTL_DEFER_SHADOW = 6,   // shadow rays
     CTL_LEVEL_START = 8,   // [RT_MAX_DEPTH + 2] first node of each level
     CTL_LEVEL_COUNT = 40,  // [RT_MAX_DEPTH + 2] nodes of each level: while the level above is shaded, the slots its
                            // child rays ASKED for (may pass the arrays' end); once the level is opened, the nodes it holds
@@ -154,11 +150,22 @@ enum {
     CTL_OVERFLOW = 127,    // sticky: a child ray did not fit the node arrays
     CTL_WORDS = 128
 };
-// Behind the control words, in the same array: the work items left to the launches with the literal box test, closest
-// hit first, then shadow rays (RT_DEFER_LIST entries each; if a launch leaves more, the second launch looks through all
-// of the level's items for the marks instead).
+// Behind the control words, in the same array:
+//  - the work queues.  Each of the four queue kinds (closest hit, shadow rays, and the same two for the launches with
+//    the literal box test) is RT_QUEUES counters, 256 bytes apart: counter q hands out the 64-ray chunks q, q + RT_QUEUES,
+//    q + 2 RT_QUEUES, ...; a wavefront starts with counter blockIdx % RT_QUEUES and moves on to the next one when its
+//    own is dry, so that the atomics of a launch are spread over RT_QUEUES addresses instead of queuing up at one;
+//  - the work items left to the launches with the literal box test, closest hit first, then shadow rays (RT_DEFER_LIST
+//    entries each; if a launch leaves more, the second launch looks through all of the level's items for the marks).
+#ifndef RT_QUEUES
+#define RT_QUEUES 8
+#endif
+#define RT_QUEUE_STRIDE 64 /* words between two counters */
+#define RT_QUEUE_WORDS (4 * RT_QUEUES * RT_QUEUE_STRIDE)
+#define RT_QUEUE_WORD(kind, q) (CTL_WORDS + ((kind) * RT_QUEUES + (q)) * RT_QUEUE_STRIDE)
 #define RT_DEFER_LIST 16384
-#define RT_CTL_BYTES ((CTL_WORDS + 2 * RT_DEFER_LIST) * sizeof(uint32_t))
+#define RT_DEFER_WORD(shadow) (CTL_WORDS + RT_QUEUE_WORDS + ((shadow) ? RT_DEFER_LIST : 0))
+#define RT_CTL_BYTES ((CTL_WORDS + RT_QUEUE_WORDS + 2 * RT_DEFER_LIST) * sizeof(uint32_t))
 
 // Node kinds written by the shade kernel.
 enum { NODE_DONE = 0, NODE_MIRROR = 1, NODE_GLASS = 2 };
