@@ -446,6 +446,15 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     int sp = 0, lo = 0;  // stack entries [lo, sp) are in the LDS ring, [0, lo) in global memory
     int hShape = -1, hTri = -1;
     float hu = 0.0f, hv = 0.0f;
+    // Splitting shadow rays.  A launch ends with its longest rays: one ray in a thousand makes ten times the average
+    // number of tests, and when such a ray starts late, the whole machine waits for one lane.  Whether a shadow ray is
+    // blocked does not depend on the order of its tests, so once the queue is dry, lanes without a ray take over the
+    // oldest stack entry (the largest untouched subtree) of lanes that still walk: same ray, same space, a walk of
+    // its own that ends with that subtree.  The ray's visibility byte is set to "visible" when the ray starts and
+    // cleared by whichever part finds an occluder; a hit ends the other parts of the ray in the same wavefront.
+    // Counter launches walk every ray in one piece, in the reference's order.
+    constexpr bool kSplit = ANY && !COUNT;
+    int floorAt = 0;  // first stack entry of the space the ray is walked in now (behind the marker while inside a mesh)
 
 #ifdef RT_STAMPS  // diagnostic build: shader-clock cycles per section of the loop, summed per wavefront (COUNT launches only)
     unsigned stampAcc[16] = {}, stampCnt[16] = {};
@@ -492,6 +501,18 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
         const bool leaf = RT_REF_IS_LEAF(r);
         cur = leaf ? ((r & RT_REF_TAG_MASK) | f) : r;
         end = f + RT_REF_LEAF_COUNT(r);
+    };
+
+    // A finished part of a shadow ray (kSplit): an occluder clears the ray's visibility byte, a miss leaves it alone.
+    auto publishShadow = [&]() {
+        if (kDefer && hShape == HIT_DEFERRED) {
+            const unsigned at = atomicAdd(P.ctl + CTL_DEFER_SHADOW, 1u);
+            if (at < (unsigned)RT_DEFER_LIST) deferList[at] = (uint32_t)item;
+            P.vis[item] = VIS_DEFERRED;
+        } else if (hShape != -1) {
+            P.vis[item] = 0;
+        }
+        item = -1;
     };
 
     while (true) {
@@ -563,6 +584,8 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     hShape = -1;
                     hTri = -1;
                     hu = hv = 0.0f;
+                    floorAt = 0;
+                    if (kSplit) P.vis[item] = 1;
                     sp = 0;
                     lo = 0;
                     // cudaTracer/Scene.cuh:38-39: the walk starts with the root's box test
@@ -795,9 +818,10 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     gsave[1 * kWave] = make_uint2(__float_as_uint(o.z), __float_as_uint(d.x));
                     gsave[2 * kWave] = make_uint2(__float_as_uint(d.y), __float_as_uint(d.z));
                     gsave[3 * kWave] = make_uint2(__float_as_uint(inv.x), __float_as_uint(inv.y));
-                    gsave[4 * kWave] = make_uint2(__float_as_uint(inv.z), 0u);
+                    gsave[4 * kWave] = make_uint2(__float_as_uint(inv.z), (unsigned)floorAt);
                     gsave[5 * kWave] = make_uint2(TAG_SHAPE | nextShape, end);
                     push(STACK_MESH_EXIT, idx);
+                    floorAt = sp;
                     const V3 wo = o, wd = d;
                     const float pa = ((wo.x * m0.x + wo.y * m1.x) + wo.z * m2.x) + m3.x;
                     const float pb = ((wo.x * m0.y + wo.y * m1.y) + wo.z * m2.y) + m3.y;
@@ -832,15 +856,75 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                         o = mk(__uint_as_float(e0.x), __uint_as_float(e0.y), __uint_as_float(e1.x));
                         d = mk(__uint_as_float(e1.y), __uint_as_float(e2.x), __uint_as_float(e2.y));
                         inv = mk(__uint_as_float(e3.x), __uint_as_float(e3.y), __uint_as_float(e4.x));
+                        floorAt = (int)e4.y;
                             end = c.y;
                         cur = (c.x & IDX_MASK) < c.y ? c.x : CUR_POP;
                     } else {
                         if (COUNT) cNode++;
+                        if (kSplit && sp < floorAt) floorAt = sp;  // popped past entries given away earlier
                         if (__uint_as_float(e.y) < tMax) enter(e.x);
                     }
                 }
             }
             STAMP(9);  // pops
+            if (kSplit && exhausted) {
+                // ---- a part that has found an occluder ends the other parts of its ray; finished parts free their lanes
+                const bool fin = item >= 0 && cur == CUR_DONE;
+                unsigned long long hitM = __ballot(fin && hShape != -1 && hShape != HIT_DEFERRED);
+                while (hitM != 0ull) {
+                    const int from = __ffsll((long long)hitM) - 1;
+                    hitM &= hitM - 1ull;
+                    const int blocked = __builtin_amdgcn_readlane(item, from);
+                    if (item == blocked && cur != CUR_DONE) {
+                        cur = CUR_DONE;
+                        item = -1;
+                    }
+                }
+                if (fin) publishShadow();
+                // ---- lanes without a ray take over the oldest entry of lanes that walk
+                const bool taker = item < 0;
+                const bool giver = item >= 0 && cur != CUR_DONE && sp > floorAt;
+                const unsigned long long takeM = __ballot(taker), giveM = __ballot(giver);
+                if (takeM != 0ull && giveM != 0ull) {
+                    unsigned n = (unsigned)__popcll(takeM) < (unsigned)__popcll(giveM) ? (unsigned)__popcll(takeM) : (unsigned)__popcll(giveM);
+                    n = n < (unsigned)kTriPart ? n : (unsigned)kTriPart;
+                    const unsigned gr = laneRank(giveM), tr = laneRank(takeM);
+                    if (giver && gr < n) {
+                        const int at = floorAt;
+                        const bool inRing = at >= lo;
+                        const uint2 e = inRing ? stk[(at & ringMask) * kWave] : gstk[(size_t)at * kWave];
+                        // the entry stays where it is, as one that is never entered
+                        const uint2 dead = make_uint2(e.x, __float_as_uint(kInf));
+                        if (inRing)
+                            stk[(at & ringMask) * kWave] = dead;
+                        else
+                            gstk[(size_t)at * kWave] = dead;
+                        floorAt = at + 1;
+                        rayBuf[2 * gr] = make_float4(o.x, o.y, o.z, tMax);
+                        rayBuf[2 * gr + 1] = make_float4(d.x, d.y, d.z, __uint_as_float(e.x));
+                        tBuf[2 * gr] = __int_as_float(item);
+                        tBuf[2 * gr + 1] = __uint_as_float(e.y);
+                    }
+                    __syncthreads();
+                    if (taker && tr < n) {
+                        const float4 A = rayBuf[2 * tr], B = rayBuf[2 * tr + 1];
+                        const float entry = tBuf[2 * tr + 1];
+                        o = mk(A.x, A.y, A.z);
+                        tMax = A.w;
+                        d = mk(B.x, B.y, B.z);
+                        inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        hShape = -1;
+                        sp = 0;
+                        lo = 0;
+                        floorAt = 0;
+                        if (entry < tMax) {  // the box test the entry stands for, against the ray's reach
+                            item = __float_as_int(tBuf[2 * tr]);
+                            enter(__float_as_uint(B.w));
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
             // keep going while most lanes still work; once the queue is dry, until all are done
             const unsigned long long busy = __ballot(cur != CUR_DONE);
             if (busy == 0ull) break;
@@ -848,7 +932,9 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
         }
 
         // ---- finished lanes publish their result and give up their ray -----
-        if (item >= 0 && cur == CUR_DONE) {
+        if (kSplit) {
+            if (item >= 0 && cur == CUR_DONE) publishShadow();
+        } else if (item >= 0 && cur == CUR_DONE) {
             if (COUNT && P.tileCost) {
                 // box + triangle tests of this ray, booked on the frame tile of its pixel (primary rays and the shadow
                 // rays of primary hits; deeper rays are not attributed)
