@@ -437,6 +437,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     unsigned chunkNext = 0, chunkEnd = 0;
     unsigned dryQueues = 0;  // counters this wavefront has found dry, starting with its own (blockIdx % RT_QUEUES)
     bool exhausted = false;
+    unsigned drainSteps = 0;
 
     // per-lane ray state
     int item = -1;  // work item (node index or shadow index); -1 = no ray
@@ -867,7 +868,8 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                 }
             }
             STAMP(9);  // pops
-            if (kSplit && exhausted) {
+            // (every fourth iteration: entries are handed on a little later, and the iterations in between stay short)
+            if (kSplit && exhausted && (++drainSteps & 3u) == 0u) {
                 // ---- a part that has found an occluder ends the other parts of its ray; finished parts free their lanes
                 const bool fin = item >= 0 && cur == CUR_DONE;
                 unsigned long long hitM = __ballot(fin && hShape != -1 && hShape != HIT_DEFERRED);
