@@ -333,7 +333,7 @@ def main():
         cost_all = tile_cost.to(comm_dev).to(torch.int64)
         dist.all_reduce(cost_all)
         cost_all = cost_all.cpu()
-        lists = mg.balanced_assignment(cost_all, world)
+        lists = [mg.center_out(l, w, h) for l in mg.balanced_assignment(cost_all, world)]  # equal cost per GPU, rendered centre first
         loads = [int(cost_all[l].sum()) for l in lists]
         inter = [int(cost_all[l].sum()) for l in mg.interleaved_assignment(w, h, world)]
         balance = {"max_over_mean_cost_balanced": max(loads) / (sum(loads) / world), "max_over_mean_cost_interleaved": max(inter) / (sum(inter) / world)}

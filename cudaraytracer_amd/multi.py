@@ -116,6 +116,19 @@ def quantize8(x):
     return (x * 256.0).nan_to_num(0.0, 255.0, 0.0).clamp_(0.0, 255.0).to(torch.uint8)
 
 
+def center_out(tiles, width, height):
+    """The same tiles, in the order the library itself hands tiles out: by the distance of the tile's centre from the
+    image centre (ties by tile number).  WHICH tiles a rank renders is what balances the load; the ORDER within its list
+    decides how the rays of neighbouring tiles share the caches and whether the long rays start first - a list left in
+    order of falling cost renders about a tenth slower."""
+    t = torch.as_tensor(tiles, dtype=torch.int64).flatten()
+    tx, _ = tile_grid(width, height)
+    dx = (t % tx) * 2 * TILE + TILE - width
+    dy = (t // tx) * 2 * TILE + TILE - height
+    key = (dx * dx + dy * dy) * (int(t.max()) + 1 if t.numel() else 1) + t
+    return t[torch.argsort(key)]
+
+
 class TileGather:
     """Collects the tiles each rank rendered into the full frame on rank 0.
 

@@ -185,3 +185,19 @@ def test_balanced_lists_ragged_frames_and_frames_in_flight(world, tmp_path):
     out = tmp_path / "ok"
     mp.spawn(_worker2, args=(world, _free_port(), str(out)), nprocs=world, join=True)
     assert out.read_text() == "ok"
+
+
+def test_center_out_keeps_the_tiles_and_orders_them_like_the_library():
+    """multi.center_out: the same tiles, nearest to the image centre first (the key of rt_capi.cpp's centre-out table)."""
+    import torch
+
+    from cudaraytracer_amd import multi as mg
+
+    w, h = 100, 37
+    tx, ty = mg.tile_grid(w, h)
+    tiles = torch.randperm(tx * ty)[: tx * ty // 2]
+    out = mg.center_out(tiles, w, h)
+    assert sorted(out.tolist()) == sorted(tiles.tolist())
+    key = [((int(t) % tx) * 16 + 8 - w) ** 2 + ((int(t) // tx) * 16 + 8 - h) ** 2 for t in out.tolist()]
+    assert key == sorted(key)
+    assert mg.center_out([], w, h).numel() == 0
