@@ -6,14 +6,19 @@
 //   traceKernel<closest>  persistent 64-lane wavefronts; every LANE owns one ray
 //                         and gets the next one from an atomic work queue after
 //                         its ray ends (wave-level chunks of the queue keep
-//                         neighbouring pixels in one wave); two-level BVH walk,
-//                         box tests per lane, leaf triangles tested by all 64
-//                         lanes together, per-lane stack in an LDS ring
+//                         neighbouring pixels in one wave; the queue is eight
+//                         counters, so that a launch does not queue up at one
+//                         address); two-level BVH walk, box tests per lane, leaf
+//                         triangles tested by all 64 lanes together, per-lane
+//                         stack in an LDS ring.  Large frames: two launches,
+//                         the box test in min / max form for rays with a
+//                         finite reciprocal direction, literally for the rest
 //   shadeKernel           hit -> surface (st, normal, textures) -> either a
 //                         shading context + shadow work, or child rays
 //                         (ballot-compacted into the next level's queue)
 //   traceKernel<any hit>  shadow rays: (diffuse hit, light) pairs, ray rebuilt
-//                         from the shading context
+//                         from the shading context; once the queue is dry, idle
+//                         lanes take over subtrees of the rays still walked
 //   accumKernel           Blinn-Phong sum over the lights in light order
 //   resolveKernel         mirror / glass nodes combined bottom-up
 //   finalizeKernel        sample average, gamma, float4 store
