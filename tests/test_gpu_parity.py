@@ -481,6 +481,8 @@ def test_bad_render_arguments(gpu_ctx):
         scene.opts.contents.samples = 65
         with pytest.raises(rt.RtError):
             gpu_ctx.render(dscene, scene.opts, scene.camera, surf, pitch)
+        with pytest.raises(rt.RtError):
+            gpu_ctx.set_box_test_split(-1)
     finally:
         gpu_ctx.free(surf)
         gpu_ctx.free_scene(dscene)
