@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--lights", type=int, default=1)
     ap.add_argument("--max-depth", type=int, default=0)
     ap.add_argument("--reference-bvh", action="store_true", help="build BVHs with the reference's FLT_MIN-clamped boxes")
+    ap.add_argument("--bvh", choices=("sah", "median"), default="sah",
+                    help="mesh BVH of the headline scene: cut by the binned surface-area heuristic (leaves <= 8 triangles) or by the "
+                         "reference's median cut (leaves <= 10); same image either way")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target duration of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--tile-balance", choices=("cost", "interleaved"), default="cost",
@@ -271,7 +274,8 @@ def main():
     scene = None
     t_build = time.perf_counter()
     if rank == 0:
-        scene = rt.HostScene(args.scene, w, h, args.size, args.lights, args.max_depth, tight_bvh=not args.reference_bvh)
+        scene = rt.HostScene(args.scene, w, h, args.size, args.lights, args.max_depth, tight_bvh=not args.reference_bvh,
+                             sah_bvh=args.bvh == "sah" and not args.reference_bvh)
     t_build = time.perf_counter() - t_build
     if multi:
         from cudaraytracer_amd import multi as mg
@@ -471,6 +475,9 @@ def main():
         dscene = None
         assets = synth_assets.write_assets(tempfile.mkdtemp(prefix="rt_assets_"))
         plans = [
+            ("cfg 2 on the reference's median-cut tree (cudaTracer/BVH.h:104-181, leaves <= 10) with tight boxes: the same soup, the same "
+             "image, the tree shape the reference builds",
+             ("soup", w, h, args.size, args.lights, args.max_depth), {"tight_bvh": True}),
             ("cfg 2 on the reference's own BVH: the same soup with FLT_MIN-clamped boxes (cudaTracer/BoundingBox.cuh:25-27)",
              ("soup", w, h, args.size, args.lights, args.max_depth), {"tight_bvh": False}),
             ("cfg 1: 16x16 grid of cube meshes (one mesh BVH each) under a scene BVH, 640x480, 4 lights, maxDepth 5",
@@ -525,7 +532,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.scene}: {args.size} random triangles in one mesh BVH, {w}x{h}, {args.lights} light(s), "
                                    f"primary + shadow rays, samples 1, maxDepth {args.max_depth}, "
-                                   f"{'reference (FLT_MIN-clamped)' if args.reference_bvh else 'tight-bounds'} median-split BVH; "
+                                   + ("the reference's median-cut BVH with its FLT_MIN-clamped boxes; " if args.reference_bvh else
+                                      "tight-bounds BVH cut by the binned surface-area heuristic, leaves <= 8 triangles (rt_mesh_bvh_build's rule; "
+                                      "the reference's median-cut tree is under other_workloads); " if args.bvh == "sah" else
+                                      "tight-bounds BVH, the reference's median cut, leaves <= 10; ") +
                                    "EXACT build of the kernels (bit-identical to the reference's formulas)",
                        "rays_per_frame": rays, "primary": cnt["primary"], "shadow": cnt["shadow"],
                        "tile_sharding": ("single GPU" if not multi else

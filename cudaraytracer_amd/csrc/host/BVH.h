@@ -197,6 +197,8 @@ class BvhFactory {
         constexpr int kBins = 32;
         float bestCost = FLT_MAX;
         int bestDim = -1, bestBin = -1;
+        const bool wantTwoLeaves = end - start <= 2 * threshold;
+        bool haveTwoLeaves = false;
         for (int dim = 0; dim < 3; ++dim) {
             const float lo = centroidBounds.bbmin[dim], extent = centroidBounds.bbmax[dim] - lo;
             if (!(extent > 0.0f)) continue;
@@ -224,11 +226,16 @@ class BvhFactory {
                 if (count[b - 1]) acc = BoundingBox::unionn(acc, box[b - 1]);
                 n += count[b - 1];
                 if (n == 0 || rightCount[b] == 0) continue;
-                const float cost = halfArea(acc) * (float)n + rightArea[b] * (float)rightCount[b];
-                if (cost < bestCost) {
+                // A leaf costs the same whatever it holds (its triangles are tested side by side), so a range that
+                // can become two leaves does so by the cut with the smallest surface, not the smallest area x count.
+                const bool twoLeaves = n <= threshold && rightCount[b] <= threshold;
+                if (wantTwoLeaves && !twoLeaves && haveTwoLeaves) continue;
+                const float cost = wantTwoLeaves && twoLeaves ? halfArea(acc) + rightArea[b] : halfArea(acc) * (float)n + rightArea[b] * (float)rightCount[b];
+                if (cost < bestCost || (wantTwoLeaves && twoLeaves && !haveTwoLeaves)) {
                     bestCost = cost;
                     bestDim = dim;
                     bestBin = b;
+                    haveTwoLeaves = wantTwoLeaves && twoLeaves;
                 }
             }
         }
