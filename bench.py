@@ -485,7 +485,9 @@ def main():
             ("cfg 3: OBJ barrel (488 triangles, three 1024x1024 maps) in three instances, one a mirror, textured plane, mirror and "
              "glass balls, 1920x1080, 10 lights, maxDepth 2 (stand-in asset files of the reference's shape)",
              ("barrel", 1920, 1080, 0, 10, 2), {"asset_dir": assets, "tight_bvh": True}),
-            ("cfg 4: height field of 9 999 392 triangles in one mesh BVH built on the device, 3840x2160, 1 light",
+            ("cfg 4: height field of 9 999 392 triangles in one mesh BVH cut by the surface-area heuristic (host build), 3840x2160, 1 light",
+             ("heightfield", 3840, 2160, 10000000, 1, 0), {"tight_bvh": True, "sah_bvh": True}),
+            ("cfg 4 with the reference's median-cut tree, built on the device (rt_set_device_bvh)",
              ("heightfield", 3840, 2160, 10000000, 1, 0), {"tight_bvh": True, "device_bvh": True}),
             ("cfg 5: default-scene analogue (sphere field, mirror and glass balls, textured plane, three mesh instances), "
              "1920x1080, 16 lights, maxDepth 4",
