@@ -749,6 +749,21 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                         asm volatile("" ::"v"(x0), "v"(x1));
                     }
 #endif
+#ifdef RT_X_LOAD  // sensitivity experiment: RT_X_LOAD extra 16-byte loads per node step, from the line that just arrived
+                    {
+#ifdef RT_X_LOAD_UNIFORM  // every lane reads the same line
+                        const float4* q = blob4 + ((size_t)(lane & 3) << 2);
+#else
+                        const float4* q = p;
+#endif
+                        asm volatile("" : "+v"(q));
+#pragma unroll
+                        for (int i = 0; i < RT_X_LOAD; ++i) {
+                            const float4 x = q[i & 3];
+                            asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
+                        }
+                    }
+#endif
 #ifdef RT_X_SALU  // sensitivity experiment: extra scalar instructions per node step
                     {
                         unsigned s0 = (unsigned)level;
