@@ -13,6 +13,11 @@
 // order to the compiler (BVH.h:146-149); MSVC and g++ both evaluate right to
 // left, so the second half is numbered first here, explicitly.
 //
+// Threads.  The two halves of a range share nothing: each orders its own part of primitiveInfo, and where its leaves
+// go in orderedPrims follows from the sizes of the ranges alone (the second half's primitives come first).  So large
+// ranges hand their second half to another thread (at most 16, or RT_BVH_THREADS), and the arrays that come out are
+// the same for any number of threads.
+//
 // Bounds mode.  REFERENCE_BOUNDS reproduces the reference builder bit for bit,
 // including its empty box whose max corner starts at FLT_MIN: every box is then
 // stretched up to ~0 on each axis, so geometry at negative coordinates gets
@@ -24,8 +29,14 @@
 #define RT_HOST_BVH_H
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <deque>
+#include <exception>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 #include "BoundingBox.h"
@@ -90,6 +101,8 @@ struct InterNode {
     int splitAxis = -1;
     int firstPrimOffset = -1;
     int primitiveCnt = -1;
+    int subtreeNodes = 1;  // this node and everything below it
+    int subtreeDepth = 0;  // levels below this node
     enum NodeTypes { NOT_SET = -1, LEAF, INTERIOR };
     NodeTypes nodeType = NOT_SET;
 
@@ -105,6 +118,8 @@ struct InterNode {
         bb = BoundingBox::unionn(c0->bb, c1->bb);
         splitAxis = axis;
         primitiveCnt = primCnt;
+        subtreeNodes = 1 + c0->subtreeNodes + c1->subtreeNodes;
+        subtreeDepth = 1 + (std::max)(c0->subtreeDepth, c1->subtreeDepth);
         nodeType = INTERIOR;
     }
 };
@@ -137,31 +152,83 @@ class BvhFactory {
     }
 
    private:
-    std::vector<std::unique_ptr<InterNode>> pool;
+    // Nodes of the tree under construction.  Every thread allocates from an arena of its own.
+    typedef std::deque<InterNode> Arena;
+    std::vector<std::unique_ptr<Arena>> arenas;
+    std::mutex arenasMutex;
+    std::atomic<int> spareThreads{0};
+    std::exception_ptr failure;  // first exception of a helper thread (guarded by arenasMutex)
+    static constexpr int kThreadGrain = 1 << 15;  // smallest range worth a thread of its own
+
+    Arena& newArena() {
+        std::lock_guard<std::mutex> lock(arenasMutex);
+        arenas.emplace_back(new Arena());
+        return *arenas.back();
+    }
+    static int buildThreads() {
+        if (const char* e = std::getenv("RT_BVH_THREADS")) {
+            const int n = std::atoi(e);
+            if (n >= 1) return (std::min)(n, 64);
+        }
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (int)(std::min)(hw ? hw : 1u, 16u);
+    }
 
     void build() {
         if (primitives.empty()) throw std::invalid_argument("BvhFactory: no primitives");
-        orderedPrims.reserve(primitives.size());
-        orderedIdx.reserve(primitives.size());
-        int totalNodes = 0;
-        InterNode* root = recursive(0, (int)primitives.size(), totalNodes, 0);
-        nodes = std::vector<LinearNode>(totalNodes);
+        orderedPrims.resize(primitives.size());
+        orderedIdx.resize(primitives.size());
+        spareThreads = buildThreads() - 1;
+        InterNode* root = recursive(0, (int)primitives.size(), 0, newArena());
+        if (failure) std::rethrow_exception(failure);
+        depth = root->subtreeDepth;
+        nodes = std::vector<LinearNode>(root->subtreeNodes);
         int offset = 0;
         flattenBvhTree(root, &offset);
-        pool.clear();
+        arenas.clear();
     }
 
-    InterNode* recursive(const int start, const int end, int& totalNodes, int level) {
-        pool.emplace_back(new InterNode());
-        InterNode* node = pool.back().get();
-        totalNodes++;
-        depth = (std::max)(depth, level);
+    // Builds both halves of [start, end) cut at mid: the second half first (see the head of this file), on another
+    // thread when the range is large and a thread is to spare.  The second half's leaves take the front of the
+    // range's slots in orderedPrims.
+    void halves(const int start, const int mid, const int end, const int orderedBase, Arena& arena, InterNode*& first, InterNode*& second) {
+        const int firstBase = orderedBase + (end - mid);
+        if (end - start >= kThreadGrain && spareThreads.fetch_sub(1) > 0) {
+            std::thread helper([&]() {
+                try {
+                    second = recursive(mid, end, orderedBase, newArena());
+                } catch (...) {
+                    std::lock_guard<std::mutex> lock(arenasMutex);
+                    if (!failure) failure = std::current_exception();
+                    second = nullptr;
+                }
+            });
+            try {
+                first = recursive(start, mid, firstBase, arena);
+            } catch (...) {
+                helper.join();
+                spareThreads.fetch_add(1);
+                throw;
+            }
+            helper.join();
+            spareThreads.fetch_add(1);
+            if (!second) std::rethrow_exception(failure);
+            return;
+        }
+        if (end - start >= kThreadGrain) spareThreads.fetch_add(1);  // none to spare: give the claim back
+        second = recursive(mid, end, orderedBase, arena);
+        first = recursive(start, mid, firstBase, arena);
+    }
+
+    InterNode* recursive(const int start, const int end, const int orderedBase, Arena& arena) {
+        arena.emplace_back();
+        InterNode* node = &arena.back();
         BoundingBox bb = emptyBox(boundsMode);
         for (int i = start; i < end; ++i) bb = BoundingBox::unionn(bb, primitiveInfo[i].bb);
 
         const int primCnt = end - start;
         if (primCnt <= threshold) {
-            leaf(bb, primCnt, start, end, node);
+            leaf(bb, primCnt, start, end, orderedBase, node);
             return node;
         }
         BoundingBox centroidBounds = emptyBox(boundsMode);
@@ -169,20 +236,24 @@ class BvhFactory {
             centroidBounds = BoundingBox::unionn(centroidBounds, primitiveInfo[i].bb.centroid());
         const int dim = centroidBounds.maxExtent();
         if (centroidBounds.bbmax[dim] == centroidBounds.bbmin[dim]) {
-            leaf(bb, primCnt, start, end, node);
+            leaf(bb, primCnt, start, end, orderedBase, node);
             return node;
         }
+        InterNode *first = nullptr, *second = nullptr;
         if (splitRule == BINNED_SAH) {
             int sahDim = dim;
             const int mid = sahPartition(start, end, centroidBounds, &sahDim);
             if (mid > start && mid < end) {
-                InterNode* second = recursive(mid, end, totalNodes, level + 1);
-                InterNode* first = recursive(start, mid, totalNodes, level + 1);
+                halves(start, mid, end, orderedBase, arena, first, second);
                 node->interior(sahDim, primCnt, first, second);
                 return node;
             }
         }
-        interior(primCnt, start, end, dim, node, totalNodes, level);
+        const int mid = (start + end) / 2;
+        std::nth_element(primitiveInfo.begin() + start, primitiveInfo.begin() + mid, primitiveInfo.begin() + end,
+                         [dim](const PreNode& a, const PreNode& b) { return a.bb.centroid()[dim] < b.bb.centroid()[dim]; });
+        halves(start, mid, end, orderedBase, arena, first, second);
+        node->interior(dim, primCnt, first, second);
         return node;
     }
 
@@ -252,25 +323,14 @@ class BvhFactory {
         return b < 0 ? 0 : (b >= bins ? bins - 1 : b);
     }
 
-    void interior(const int primCnt, const int start, const int end, const int dim, InterNode* node, int& totalNodes,
-                  int level) {
-        const int mid = (start + end) / 2;
-        std::nth_element(primitiveInfo.begin() + start, primitiveInfo.begin() + mid, primitiveInfo.begin() + end,
-                         [dim](const PreNode& a, const PreNode& b) { return a.bb.centroid()[dim] < b.bb.centroid()[dim]; });
-        InterNode* second = recursive(mid, end, totalNodes, level + 1);
-        InterNode* first = recursive(start, mid, totalNodes, level + 1);
-        node->interior(dim, primCnt, first, second);
-    }
-
-    void leaf(const BoundingBox& bb, const int primCnt, const int start, const int end, InterNode* node) {
+    void leaf(const BoundingBox& bb, const int primCnt, const int start, const int end, const int orderedBase, InterNode* node) {
         if (primCnt > 65535) throw std::length_error("BvhFactory: leaf exceeds the 16-bit primitive count of LinearNode");
-        const int firstPrimOffset = (int)orderedPrims.size();
         for (int i = start; i < end; ++i) {
             const int idx = primitiveInfo[i].primIdx;
-            orderedPrims.push_back(primitives[idx]);
-            orderedIdx.push_back(idx);
+            orderedPrims[orderedBase + (i - start)] = primitives[idx];
+            orderedIdx[orderedBase + (i - start)] = idx;
         }
-        node->leaf(firstPrimOffset, primCnt, bb);
+        node->leaf(orderedBase, primCnt, bb);
     }
 
     int flattenBvhTree(InterNode* node, int* offset) {

@@ -363,6 +363,8 @@ int rt_set_device_bvh(rt_ctx* ctx, int threshold, int tightBounds);
  * `leafThreshold` (1..63) is the most triangles a leaf gets unless their centroids coincide.  `order[k]` receives the
  * index (into `triangles`) of the triangle that belongs in leaf slot k: the caller hands RtMesh.triangles over in that
  * order.  `nodes` must hold `nodeCapacity` entries; 2 * triangleCnt - 1 always suffice.
+ * Large meshes are built on several threads (as many as the machine reports, at most 16; the environment variable
+ * RT_BVH_THREADS overrides the number, 1 = the calling thread alone); the result does not depend on the number.
  * Returns RT_ERR_INVALID / RT_ERR_LIMIT with the message in rt_last_error(NULL). */
 #define RT_BVH_MEDIAN_CUT 0
 #define RT_BVH_BINNED_SAH 1

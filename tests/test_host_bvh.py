@@ -153,6 +153,40 @@ def test_surface_area_tree_is_valid_and_cheaper(rtlib):
     assert sah < 0.8 * median
 
 
+def big_mesh(n_tris, seed):
+    """Like clustered_mesh, filled in through numpy: large enough for the builder to use several threads."""
+    rng = np.random.default_rng(seed)
+    centres = rng.uniform(-40, 40, (6, 3))
+    spread = np.array([0.3, 0.5, 1.0, 2.0, 4.0, 30.0])
+    k = rng.integers(0, 6, n_tris)
+    c = centres[k] + rng.normal(0, 1, (n_tris, 3)) * spread[k, None]
+    assert C.sizeof(N.RtVertex) == 56 and N.RtVertex.position.offset % 4 == 0
+    at = N.RtVertex.position.offset // 4
+    v = np.zeros((3 * n_tris, 14), dtype=np.float32)
+    v[:, at : at + 3] = (c[:, None, :] + rng.uniform(-0.2, 0.2, (n_tris, 3, 3))).reshape(-1, 3)
+    t = np.arange(3 * n_tris, dtype=np.int32).reshape(n_tris, 3).copy()
+    verts = (N.RtVertex * (3 * n_tris)).from_buffer(v)
+    tris = (N.RtTriangle * n_tris).from_buffer(t)
+    return verts, tris, (v, t)
+
+
+@pytest.mark.parametrize("rule", [0, 1])
+def test_tree_does_not_depend_on_the_number_of_builder_threads(rtlib, oracle, rule, monkeypatch):
+    """Ranges of 32768 primitives and more hand one half to another thread; nodes and leaf order must not change with it."""
+    n = 150_000
+    verts, tris, keep = big_mesh(n, seed=12)
+    built = {}
+    for threads in ("1", "2", "8"):
+        monkeypatch.setenv("RT_BVH_THREADS", threads)
+        nodes, cnt, order = capi_build(rtlib, verts, tris, rule, 8, 1)
+        built[threads] = (bytes(nodes)[: 32 * cnt], order)
+    assert built["1"] == built["2"] == built["8"]
+    assert sorted(built["8"][1]) == list(range(n))
+    if rule == 0:
+        ref = build_both(rtlib, oracle, verts, tris, 8, 1)["oracle"]
+        assert built["8"] == (ref[0], ref[1])
+
+
 def test_bvh_build_rejects_bad_arguments(rtlib):
     verts, tris = random_mesh(4, seed=1)
     nodes = (N.RtLinearNode * 8)()
