@@ -36,6 +36,7 @@
 #include <memory>
 #include <mutex>
 #include <stdexcept>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -193,16 +194,24 @@ class BvhFactory {
     // range's slots in orderedPrims.
     void halves(const int start, const int mid, const int end, const int orderedBase, Arena& arena, InterNode*& first, InterNode*& second) {
         const int firstBase = orderedBase + (end - mid);
-        if (end - start >= kThreadGrain && spareThreads.fetch_sub(1) > 0) {
-            std::thread helper([&]() {
-                try {
-                    second = recursive(mid, end, orderedBase, newArena());
-                } catch (...) {
-                    std::lock_guard<std::mutex> lock(arenasMutex);
-                    if (!failure) failure = std::current_exception();
-                    second = nullptr;
-                }
-            });
+        const bool claimed = end - start >= kThreadGrain && spareThreads.fetch_sub(1) > 0;
+        std::thread helper;
+        if (claimed) {
+            try {
+                helper = std::thread([&]() {
+                    try {
+                        second = recursive(mid, end, orderedBase, newArena());
+                    } catch (...) {
+                        std::lock_guard<std::mutex> lock(arenasMutex);
+                        if (!failure) failure = std::current_exception();
+                        second = nullptr;
+                    }
+                });
+            } catch (const std::system_error&) {
+                // no thread to be had (a process limit): this range is built by the calling thread
+            }
+        }
+        if (helper.joinable()) {
             try {
                 first = recursive(start, mid, firstBase, arena);
             } catch (...) {
@@ -215,7 +224,7 @@ class BvhFactory {
             if (!second) std::rethrow_exception(failure);
             return;
         }
-        if (end - start >= kThreadGrain) spareThreads.fetch_add(1);  // none to spare: give the claim back
+        if (end - start >= kThreadGrain) spareThreads.fetch_add(1);  // none to spare or none started: give the claim back
         second = recursive(mid, end, orderedBase, arena);
         first = recursive(start, mid, firstBase, arena);
     }
