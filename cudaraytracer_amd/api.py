@@ -134,10 +134,11 @@ class Experiment:
                       "transform": np.array(transform, dtype=np.float32).reshape(4, 4)},
         }
 
-    def scene(self, idx, asset_dir=None, tight_bvh=False, device_bvh=False, derive_view=False):
+    def scene(self, idx, asset_dir=None, tight_bvh=False, device_bvh=False, derive_view=False, sah_bvh=False):
         """The scene of phase idx, assembled like RayTracer::initScene (cudaTracer/RayTracer.cpp:50-78).
-        derive_view: recompute scale / aspect ratio from the phase's fov, width, height (the reference keeps the defaults')."""
-        flags = (1 if tight_bvh else 0) | (2 if device_bvh else 0) | (4 if derive_view else 0)
+        derive_view: recompute scale / aspect ratio from the phase's fov, width, height (the reference keeps the defaults').
+        sah_bvh: mesh BVHs cut by the binned surface-area heuristic instead of the reference's median cut."""
+        flags = (1 if tight_bvh else 0) | (2 if device_bvh else 0) | (4 if derive_view else 0) | (8 if sah_bvh else 0)
         h = self.lib.rth_experiment_scene(self.h, idx, asset_dir.encode() if asset_dir else None, flags)
         if not h:
             raise RtError(self.lib.rth_last_error().decode())

@@ -17,13 +17,13 @@ from .api import Experiment, RtError
 
 
 def run_phase(exp, phase_idx, rounds=1, dt=0.016, png_path=None, asset_dir=None, device=0, tight_bvh=False, device_bvh=False,
-              derive_view=False):
+              derive_view=False, sah_bvh=False):
     """Builds phase `phase_idx`, renders `rounds` frames with the C++ driver loop and returns (last frame, record)."""
     if not 0 <= phase_idx < len(exp.phases):
         raise RtError(f"experiment '{exp.name}' has {len(exp.phases)} phase(s); phase {phase_idx} does not exist")
     phase = exp.phases[phase_idx]
     t0 = time.perf_counter()
-    scene = exp.scene(phase_idx, asset_dir=asset_dir, tight_bvh=tight_bvh, device_bvh=device_bvh, derive_view=derive_view)
+    scene = exp.scene(phase_idx, asset_dir=asset_dir, tight_bvh=tight_bvh, device_bvh=device_bvh, derive_view=derive_view, sah_bvh=sah_bvh)
     t1 = time.perf_counter()
     try:
         rgba = scene.run_frames(rounds, dt, png_path=png_path, device=device)
@@ -58,6 +58,7 @@ def main(argv=None):
     ap.add_argument("--assets", default=None, help="asset directory for phases without a model (default: procedural stand-ins)")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--tight-bvh", action="store_true", help="build BVHs from a true empty box")
+    ap.add_argument("--sah-bvh", action="store_true", help="cut mesh BVHs by the binned surface-area heuristic (host build) instead of the reference's median cut")
     ap.add_argument("--device-bvh", action="store_true", help="build mesh BVHs on the GPU")
     ap.add_argument("--derive-view", action="store_true", help="re-derive scale / aspect ratio from the phase's fov, width, height")
     ap.add_argument("--strict", action="store_true", help="stop when the reader reported anything")
@@ -76,7 +77,7 @@ def main(argv=None):
         out = f"{exp.name}_{exp.phases[args.phase]['name']}.png".replace("/", "_").replace(" ", "_")
     try:
         _, record = run_phase(exp, args.phase, rounds=args.rounds, png_path=out or None, asset_dir=args.assets, device=args.device,
-                              tight_bvh=args.tight_bvh, device_bvh=args.device_bvh, derive_view=args.derive_view)
+                              tight_bvh=args.tight_bvh, device_bvh=args.device_bvh, derive_view=args.derive_view, sah_bvh=args.sah_bvh)
     except RtError as e:
         print(f"error: {e}", file=sys.stderr)
         return 1

@@ -30,11 +30,12 @@ def experiment_file(tmp_path):
     return path
 
 
-@pytest.mark.parametrize("phase,derive_view", [(0, True), (0, False), (1, True), (2, False)])
-def test_phase_renders_like_the_oracle(oracle, tmp_path, phase, derive_view):
+@pytest.mark.parametrize("phase,derive_view,sah", [(0, True, False), (0, False, False), (1, True, False), (2, False, False), (0, True, True),
+                                                   (1, True, True)])
+def test_phase_renders_like_the_oracle(oracle, tmp_path, phase, derive_view, sah):
     exp = rt.Experiment(experiment_file(tmp_path))
     assert exp.errors == []
-    scene = exp.scene(phase, derive_view=derive_view)
+    scene = exp.scene(phase, derive_view=derive_view, sah_bvh=sah, tight_bvh=sah)
     w, h = scene.width, scene.height
     png = tmp_path / "frame.png"
     rgba = scene.run_frames(1, 0.016, str(png))   # one round: lights turn by dt, render, read back, dump
