@@ -341,3 +341,49 @@ int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* streamPtr, int* degenerat
     cleanup();
     return 0;
 }
+
+// ---------------------------------------------------------------------------
+// Quad records (rt_device_format.h): one thread per half of a quad copies the child pair of one record of the pair,
+// or the record itself when it is a leaf, and turns the interior references it copies into references to quads.
+namespace {
+__global__ void quadKernel(const uint32_t* __restrict__ pairs, uint32_t pairBase, uint32_t pairCnt, uint32_t* __restrict__ quads, uint32_t quadBase) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2u * pairCnt) return;
+    const uint32_t i = t >> 1, h = t & 1u;
+    const uint32_t* rec = pairs + (size_t)i * 16 + h * 8;
+    const uint32_t ref = rec[6];
+    uint32_t out[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) out[k] = 0u;
+    uint32_t axisWord;
+    if (i == 0u && h == 1u) {
+        axisWord = RT_QUAD_NONE;  // the padding beside the tree's root record
+    } else if (RT_REF_IS_LEAF(ref)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) out[k] = rec[k];
+        axisWord = RT_QUAD_ONE;
+    } else {
+        const uint32_t* child = pairs + (size_t)(RT_REF_PAIR_UNITS(ref) - pairBase) * 16;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) out[k] = child[k];
+#pragma unroll
+        for (int k = 6; k < 16; k += 8) {
+            const uint32_t r = out[k];
+            if (!RT_REF_IS_LEAF(r)) out[k] = (r & 0x60000000u) | (RT_REF_PAIR_UNITS(r) - pairBase + quadBase);
+        }
+        axisWord = RT_REF_AXIS(ref);
+    }
+    out[7] = axisWord;
+    uint4* dst = reinterpret_cast<uint4*>(quads + (size_t)(quadBase + i) * 32 + h * 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dst[k] = make_uint4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+}
+}  // namespace
+
+int rtk_build_quads(const void* pairs, uint32_t pairBase, uint32_t pairCnt, void* quads, uint32_t quadBase, void* stream) {
+    if (pairCnt == 0) return 0;
+    const uint32_t threads = 2u * pairCnt;
+    hipLaunchKernelGGL(quadKernel, dim3((threads + 255u) / 256u), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const uint32_t*>(pairs), pairBase, pairCnt, reinterpret_cast<uint32_t*>(quads), quadBase);
+    return (int)hipGetLastError();
+}

@@ -406,6 +406,9 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
 #else
     constexpr bool kDefer = !LIT;  // rays with an infinite reciprocal direction are left to the rescue launch
 #endif
+    // The launches with the min / max box test walk quads (four grandchildren per fetch, rt_device_format.h); counter
+    // launches and the launches with the literal box test walk the sibling pairs, test for test as the reference does.
+    constexpr bool kQuad = !LIT && !COUNT;
     // the rays left to the rescue launch: listed behind the control words while the list lasts, marked in any case
     const unsigned deferred = rescue ? P.ctl[(ANY ? CTL_DEFER_SHADOW : CTL_DEFER_CLOSEST)] : 0u;
     if (rescue && deferred == 0u) return;
@@ -595,7 +598,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     sp = 0;
                     lo = 0;
                     // cudaTracer/Scene.cuh:38-39: the walk starts with the root's box test
-                    cur = useSceneBvh ? P.sceneRootRef : TAG_SHAPE;
+                    cur = useSceneBvh ? (kQuad ? P.sceneRootQuad : P.sceneRootRef) : TAG_SHAPE;
                     end = (unsigned)P.shapeCnt;
                 } else {
                     // tile pixel outside the frame: no ray, marked so that later stages skip it
@@ -723,7 +726,49 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     wNodeSteps++;
                     wNodeLanes += __popcll(nodeMask);
                 }
-                if ((int)cur >= 0) {
+                if (kQuad && (int)cur >= 0) {
+                    // One 128-byte fetch: the child pairs of both children of the node (halves A and B).  The children's
+                    // own boxes are not tested: a grandchild's box lies inside its parent's, so a ray that passes the
+                    // grandchild's test would have passed the parent's, with a smaller entry distance.
+                    const float4* p = P.quads + ((size_t)RT_REF_PAIR_UNITS(cur) << 3);
+                    const float4 A0 = p[0], A1 = p[1], A2 = p[2], A3 = p[3], B0 = p[4], B1 = p[5], B2 = p[6], B3 = p[7];
+                    const auto B = [](bool c) { return __builtin_amdgcn_ballot_w64(c); };
+                    float ta0, fa0, ta1, fa1, tb0, fb0, tb1, fb1;
+                    boxPairMinMax(A0, A1, A2, A3, o, inv, ta0, fa0, ta1, fa1);
+                    boxPairMinMax(B0, B1, B2, B3, o, inv, tb0, fb0, tb1, fb1);
+                    // split axes: of the node (orders the halves) and of its two children (order inside a half);
+                    // RT_QUAD_ONE: the child is a leaf and its half holds only itself, RT_QUAD_NONE: no such child
+                    const unsigned axP = RT_REF_AXIS(cur), axA = __float_as_uint(A1.w), axB = __float_as_uint(B1.w);
+                    const unsigned long long sx = B(inv.x < 0.0f), sy = B(inv.y < 0.0f), sz = B(inv.z < 0.0f);
+                    const unsigned long long mNP = (B(axP == 0u) & sx) | (B(axP == 1u) & sy) | (B(axP == 2u) & sz);
+                    const unsigned long long mNA = (B(axA == 0u) & sx) | (B(axA == 1u) & sy) | (B(axA == 2u) & sz);
+                    const unsigned long long mNB = (B(axB == 0u) & sx) | (B(axB == 1u) & sy) | (B(axB == 2u) & sz);
+                    const unsigned long long hA0 = B(ta0 <= fa0) & B(fa0 > 0.0f) & B(ta0 < tMax);
+                    const unsigned long long hA1 = B(ta1 <= fa1) & B(fa1 > 0.0f) & B(ta1 < tMax) & B(axA < RT_QUAD_ONE);
+                    const unsigned long long hB0 = B(tb0 <= fb0) & B(fb0 > 0.0f) & B(tb0 < tMax) & B(axB < RT_QUAD_NONE);
+                    const unsigned long long hB1 = B(tb1 <= fb1) & B(fb1 > 0.0f) & B(tb1 < tMax) & B(axB < RT_QUAD_ONE);
+                    // cudaTracer/Mesh.cuh:155-161 twice over: inside a half the record on the ray's side of the child's
+                    // split comes first, and the half on the ray's side of the node's split comes first
+                    const bool negA = __builtin_amdgcn_inverse_ballot_w64(mNA), negB = __builtin_amdgcn_inverse_ballot_w64(mNB);
+                    const bool negP = __builtin_amdgcn_inverse_ballot_w64(mNP);
+                    const unsigned rAf = __float_as_uint(negA ? A3.z : A1.z), rAs = __float_as_uint(negA ? A1.z : A3.z);
+                    const unsigned rBf = __float_as_uint(negB ? B3.z : B1.z), rBs = __float_as_uint(negB ? B1.z : B3.z);
+                    const float tAf = negA ? ta1 : ta0, tAs = negA ? ta0 : ta1, tBf = negB ? tb1 : tb0, tBs = negB ? tb0 : tb1;
+                    const unsigned long long hAf = (mNA & hA1) | (~mNA & hA0), hAs = (mNA & hA0) | (~mNA & hA1);
+                    const unsigned long long hBf = (mNB & hB1) | (~mNB & hB0), hBs = (mNB & hB0) | (~mNB & hB1);
+                    const unsigned long long h0 = (mNP & hBf) | (~mNP & hAf), h1 = (mNP & hBs) | (~mNP & hAs);
+                    const unsigned long long h2 = (mNP & hAf) | (~mNP & hBf), h3 = (mNP & hAs) | (~mNP & hBs);
+                    const unsigned r0 = negP ? rBf : rAf, r1 = negP ? rBs : rAs, r2 = negP ? rAf : rBf, r3 = negP ? rAs : rBs;
+                    const float t1 = negP ? tBs : tAs, t2 = negP ? tAf : tBf, t3 = negP ? tAs : tBs;
+                    // the first of the four that is hit is entered, the later ones wait on the stack, the next one on top
+                    if (__builtin_amdgcn_inverse_ballot_w64(h3 & (h0 | h1 | h2))) push(r3, __float_as_uint(t3));
+                    if (__builtin_amdgcn_inverse_ballot_w64(h2 & (h0 | h1))) push(r2, __float_as_uint(t2));
+                    if (__builtin_amdgcn_inverse_ballot_w64(h1 & h0)) push(r1, __float_as_uint(t1));
+                    const bool e0 = __builtin_amdgcn_inverse_ballot_w64(h0), e1 = __builtin_amdgcn_inverse_ballot_w64(h1);
+                    const bool e2 = __builtin_amdgcn_inverse_ballot_w64(h2), e3 = __builtin_amdgcn_inverse_ballot_w64(h3);
+                    enter(e0 ? r0 : (e1 ? r1 : (e2 ? r2 : r3)));
+                    if (!(e0 || e1 || e2 || e3)) cur = CUR_POP;
+                } else if ((int)cur >= 0) {
                     const float4* p = blob4 + ((size_t)RT_REF_PAIR_UNITS(cur) << 2);
                     const float4 L0 = p[0], L1 = p[1], L2 = p[2], L3 = p[3];
                     STAMP(2);  // node step: child pair arrived
@@ -757,6 +802,9 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                         const float4* q = p;
 #endif
                         asm volatile("" : "+v"(q));
+#ifdef RT_X_LOAD_ONE_LANE  // only the first lane of the node step makes the extra loads
+                        if (lane == __ffsll((long long)nodeMask) - 1)
+#endif
 #pragma unroll
                         for (int i = 0; i < RT_X_LOAD; ++i) {
                             const float4 x = q[i & 3];
@@ -853,7 +901,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                            (wd.x * m0.z + wd.y * m1.z) + wd.z * m2.z);
                     inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
                     // cudaTracer/Mesh.cuh:137-138: root box test, or all triangles in order without a BVH
-                    cur = useMeshBvhs ? m->rootRef : (TAG_TRI | m->recordBase);
+                    cur = useMeshBvhs ? (kQuad ? P.meshRootQuad[s.meshIdx] : m->rootRef) : (TAG_TRI | m->recordBase);
                     end = m->recordBase + (unsigned)m->triangleCnt;
                     if (kDefer && special(inv)) {
                         // in this mesh's space the ray runs along an axis plane: the whole ray goes to the rescue launch

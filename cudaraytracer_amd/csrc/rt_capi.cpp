@@ -129,6 +129,9 @@ struct rt_scene {
     bool ownsBlob = false;
     size_t bytes = 0;
     BlobHeader header;
+    // quad records of all BVHs (rt_device_format.h), followed by one root reference per mesh; owned by the scene
+    unsigned char* quads = nullptr;
+    size_t quadCnt = 0;
 };
 
 namespace {
@@ -839,6 +842,41 @@ int rt_scene_pack(rt_ctx* ctx, const RtSceneDesc* desc, void** blob, size_t* byt
 
 void rt_blob_free(void* blob) { std::free(blob); }
 
+namespace {
+// Builds the scene's quad records from the pair records of the blob on the device (scene BVH first, then every mesh
+// BVH) and the table of the meshes' root quads behind them.  The blob itself is only read.
+int buildQuads(rt_ctx* ctx, rt_scene* sc) {
+    const BlobHeader& hd = sc->header;
+    std::vector<DevMesh> meshes(std::max(hd.meshCnt, 0));
+    if (hd.meshCnt > 0)
+        RT_HIP(ctx, hipMemcpy(meshes.data(), sc->blob + hd.offMeshes, meshes.size() * sizeof(DevMesh), hipMemcpyDeviceToHost));
+    // a tree of n nodes has (n - 1) / 2 interior nodes, each with one pair, plus the root's pseudo pair
+    auto pairsOf = [](int nodeCnt) { return (size_t)(nodeCnt + 1) / 2; };
+    size_t total = pairsOf(hd.sceneNodeCnt);
+    std::vector<uint32_t> rootQuad(meshes.size());
+    for (size_t mi = 0; mi < meshes.size(); ++mi) {
+        rootQuad[mi] = (RT_REF_ROOT_AXIS << 29) | (uint32_t)total;
+        total += pairsOf(meshes[mi].nodeCnt);
+    }
+    if (total >= (1u << 29)) return fail(ctx, RT_ERR_LIMIT, "scene has too many BVH nodes for the packed node reference");
+    const size_t quadBytes = total * 128, tableBytes = std::max<size_t>(meshes.size(), 1) * sizeof(uint32_t);
+    RT_HIP(ctx, hipMalloc((void**)&sc->quads, quadBytes + tableBytes));
+    sc->quadCnt = total;
+    uint32_t at = 0;
+    RT_HIP(ctx, (hipError_t)rtk_build_quads(sc->blob + hd.offSceneNodes, (uint32_t)(hd.offSceneNodes / 64), (uint32_t)pairsOf(hd.sceneNodeCnt), sc->quads, at,
+                                             ctx->stream));
+    at += (uint32_t)pairsOf(hd.sceneNodeCnt);
+    for (size_t mi = 0; mi < meshes.size(); ++mi) {
+        const uint32_t n = (uint32_t)pairsOf(meshes[mi].nodeCnt);
+        RT_HIP(ctx, (hipError_t)rtk_build_quads(sc->blob + meshes[mi].offNodes, (uint32_t)(meshes[mi].offNodes / 64), n, sc->quads, at, ctx->stream));
+        at += n;
+    }
+    if (!meshes.empty()) RT_HIP(ctx, hipMemcpyAsync(sc->quads + quadBytes, rootQuad.data(), rootQuad.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+}  // namespace
+
 rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
     if (!ctx) return nullptr;
     std::vector<unsigned char> host;
@@ -895,6 +933,10 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
     sc->ownsBlob = true;
     sc->bytes = host.size();
     std::memcpy(&sc->header, host.data(), sizeof(BlobHeader));
+    if (buildQuads(ctx, sc) != RT_OK) {
+        rt_scene_free(sc);
+        return nullptr;
+    }
     return sc;
 }
 
@@ -958,6 +1000,10 @@ rt_scene* rt_scene_adopt_blob(rt_ctx* ctx, const void* devBlob, size_t bytes) {
     sc->ownsBlob = false;
     sc->bytes = bytes;
     sc->header = hd;
+    if (buildQuads(ctx, sc) != RT_OK) {
+        rt_scene_free(sc);
+        return nullptr;
+    }
     return sc;
 }
 
@@ -982,10 +1028,11 @@ int rt_scene_set_lights(rt_scene* scene, const RtLight* lights, int lightCnt) {
 
 void rt_scene_free(rt_scene* scene) {
     if (!scene) return;
-    if (scene->ownsBlob) {
+    if (scene->ownsBlob || scene->quads) {
         hipSetDevice(scene->ctx->device);
-        (void)syncFrames(scene->ctx);  // frames in flight may still read the blob
-        hipFree(scene->blob);
+        (void)syncFrames(scene->ctx);  // frames in flight may still read the blob and the quads
+        if (scene->ownsBlob) hipFree(scene->blob);
+        if (scene->quads) hipFree(scene->quads);
     }
     delete scene;
 }
@@ -1133,8 +1180,12 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
     // shadow work items are (diffuse hit, light) pairs held in 32-bit signed indices
     if (nodeCapWanted * std::max(hd.lightCnt, 1) > 0x7fffffffLL)
         return fail(ctx, RT_ERR_LIMIT, "frame too large for 32-bit shadow-ray indices (%lld path nodes x %d lights)", nodeCapWanted, hd.lightCnt);
-    p.stackEntries = hd.sceneDepth + hd.maxMeshDepth + 2;
+    // The walk over pairs holds one waiting sibling per level; the walk over quads up to three per two levels.
+    p.stackEntries = std::max(hd.sceneDepth + hd.maxMeshDepth + 2, 3 * ((hd.sceneDepth + 2) / 2) + 3 * ((hd.maxMeshDepth + 2) / 2) + 2);
     p.sceneRootRef = hd.sceneRootRef;
+    p.sceneRootQuad = RT_REF_ROOT_AXIS << 29;  // the scene BVH's quads come first
+    p.quads = reinterpret_cast<const float4*>(scene->quads);
+    p.meshRootQuad = reinterpret_cast<const uint32_t*>(scene->quads + scene->quadCnt * 128);
     p.offRecords = hd.offRecords;
     // the LDS part of the stack is a ring: a power of two
     p.stackLds = 2;

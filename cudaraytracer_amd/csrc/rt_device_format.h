@@ -25,6 +25,16 @@
 // Box values, split axes and leaf contents are untouched, so every box test
 // and the near/far visiting order are those of the original tree.
 //
+// QUADS.  Beside the blob, a scene holds one 128-byte QUAD record per sibling pair (built on the device when the scene
+// is uploaded or adopted; rtk_build_quads): the pair's two records each replaced by the pair of ITS children, so that
+// one fetch brings the boxes of a node's four grandchildren.  Half h (64 bytes, laid out like a pair) is the child
+// pair of the pair's record h with that record's split axis in the spare word of its first record; if record h is a
+// leaf, the half is the record itself plus an empty one and the axis word is RT_QUAD_ONE; for the padding beside a
+// root record the half is empty and the word is RT_QUAD_NONE.  Interior references inside quads name quads (128-byte
+// units from the start of the quad array).  The launches with the min / max box test walk quads: a box that a ray
+// hits lies inside its parent's box, so the parent's own test cannot change which leaves are reached, and the four
+// grandchildren are visited in the order the two levels of the binary walk would visit them.
+//
 // FRAME WORKSPACE.  A frame is rendered as a sequence of ray "waves" over path
 // nodes.  A path node is one invocation of the reference's recursive castRay
 // (cudaTracer/tracer.cu:15-48): level-0 nodes are the pixels of the tiles this
@@ -63,6 +73,8 @@
 #define RT_REF_AXIS(r) (((r) >> 29) & 3u)
 #define RT_REF_ROOT_AXIS 3u
 #define RT_REF_PAIR_UNITS(r) ((r)&0x1fffffffu) /* 64-byte units from the blob start */
+#define RT_QUAD_ONE 3u  /* axis word of a quad half that holds one record (a leaf child) */
+#define RT_QUAD_NONE 4u /* ... that holds none (beside a root record) */
 
 struct BlobHeader {
     uint32_t magic;
@@ -198,6 +210,9 @@ struct FrameParams {
     int32_t stackEntries;                    // per-lane traversal stack entries needed (8 bytes each)
     int32_t stackLds;                        // size of the LDS ring holding the top of the stack (a power of two)
     uint32_t sceneRootRef;
+    uint32_t sceneRootQuad;                  // the same in the quad array
+    const float4* quads;                     // quad records of all BVHs (scene first, then the meshes)
+    const uint32_t* meshRootQuad;            // [meshCnt] pseudo reference to each mesh BVH's root quad
     uint64_t offRecords;
     int32_t traceWaves;                      // wavefronts of the persistent trace kernels
     int32_t waveChunks;                      // 64-ray chunks a wavefront should get at least before another one joins in
@@ -251,6 +266,11 @@ struct RtBvhBuildJob {
 // Runs the build on `stream` and waits for it.  Returns a hipError_t value; *degenerate is set when a range's
 // centroids all coincide (the reference makes such a range one big leaf; build that mesh on the host).
 int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* stream, int* degenerate);
+
+// Quad records (see the head of this file) of one BVH: `pairs` = device address of the tree's pair records, `pairBase`
+// = their blob offset / 64 (what the references inside them count from), `pairCnt` pairs; quad i of the tree is written
+// to quads[quadBase + i] and the interior references inside become quadBase-relative.  Enqueued on `stream`.
+int rtk_build_quads(const void* pairs, uint32_t pairBase, uint32_t pairCnt, void* quads, uint32_t quadBase, void* stream);
 
 // Device address and size of the CURRENT device's copy of the library's static scratch array (the workspace of
 // rt_render_noalloc).  Returns a hipError_t value.
