@@ -69,7 +69,7 @@ constexpr int kWave = 64;
 #endif
 constexpr unsigned kChunk = RT_CHUNK;  // rays a wavefront takes from the global queue per atomic
 #ifndef RT_REFILL_LANES
-#define RT_REFILL_LANES 24  // a wavefront refills once this many lanes have finished their rays
+#define RT_REFILL_LANES 32  // a wavefront refills once this many lanes have finished their rays
 #endif
 #ifndef RT_TRI_LANES
 #define RT_TRI_LANES 12  // a triangle phase starts once this many lanes wait in a leaf
