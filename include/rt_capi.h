@@ -248,7 +248,11 @@ int rt_sync(rt_ctx* ctx);
  * cudaTracer/CudaMesh.h:49-83).  The scene is flattened into one relocatable
  * blob (index-based tables, 32-byte nodes, 48-byte triangle records); the blob
  * can also be produced on one GPU, copied device-to-device (e.g. an RCCL
- * broadcast) and adopted on another with rt_scene_adopt_blob. */
+ * broadcast) and adopted on another with rt_scene_adopt_blob.  Beside the
+ * blob a scene owns a second node array that rt_scene_upload and
+ * rt_scene_adopt_blob build on the device from the blob's nodes (128 bytes per
+ * interior node: the boxes of a node's four grandchildren in one record, which
+ * the trace kernels fetch at once); the blob itself is only read. */
 rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc);
 /* Host-side flattening only: *blob is malloc'ed (free with rt_blob_free). */
 int rt_scene_pack(rt_ctx* ctx, const RtSceneDesc* desc, void** blob, size_t* bytes);
