@@ -352,7 +352,7 @@ class Context:
     def stream_wait_frame(self, stream_ptr=None, frames_ago=0):
         self._check(self.lib.rt_stream_wait_frame(self.ctx, stream_ptr, frames_ago), "rt_stream_wait_frame")
 
-    def set_box_test_split(self, min_rays=1 << 18):
+    def set_box_test_split(self, min_rays=100000):
         """Level-0 traces of at least this many primary rays run as two launches (min / max box test, then the literal one)."""
         self._check(self.lib.rt_set_box_test_split(self.ctx, min_rays), "rt_set_box_test_split")
 

@@ -83,7 +83,7 @@ struct rt_ctx {
     int framesInFlight = 1;
     unsigned long long frameCounter = 0;  // frames issued so far
     int pathBudget = 3;  // node arrays hold pathBudget x pixels when the scene has mirror / glass materials
-    int splitSlots = 1 << 18;             // rt_set_box_test_split
+    int splitSlots = 100000;              // rt_set_box_test_split
     int ldsStack = RT_LDS_STACK_DEFAULT;  // traversal stack entries kept in LDS (older ones move to global memory)
     int maxWavesPerCu = 0;                // 0 = as many as are resident
     uint32_t sampleSeed = 1234;

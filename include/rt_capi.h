@@ -426,10 +426,10 @@ int rt_set_lds_stack(rt_ctx* ctx, int entries);
 /* Box test of the EXACT build.  The reference's slab test (cudaTracer/BoundingBox.cuh:115-139) equals its min / max
  * form - fewer instructions - bit for bit unless a plane distance is a NaN, which takes an infinite reciprocal
  * direction.  The trace of a frame's primary rays, and of their shadow rays, therefore runs as two launches when the
- * call renders at least `minRays` primary rays (default 262144; INT_MAX = never): the first walks the rays with a
- * finite reciprocal direction with the min / max form, the second the others with the literal form (it ends at once
- * when there are none).  Smaller frames and reflection levels use the literal form in one launch: a kernel boundary
- * costs more than they would save.  Results do not depend on it, bit for bit.  No counterpart in the reference. */
+ * call renders at least `minRays` primary rays (default 100000; INT_MAX = never): the first walks the rays with a
+ * finite reciprocal direction with the min / max form, four grandchildren per node step, the second the others with
+ * the literal form (it ends at once when there are none).  Smaller frames and reflection levels use the literal form
+ * in one launch: with many such frames in flight the extra launches cost more than the shorter walk saves.  Results do not depend on it, bit for bit.  No counterpart in the reference. */
 int rt_set_box_test_split(rt_ctx* ctx, int minRays);
 
 /* Frames in flight (1..16, default 1).  With 1, rt_render enqueues the frame on the

@@ -25,6 +25,7 @@ ap.add_argument("--reference-bvh", action="store_true")
 ap.add_argument("--lds-stack", type=int, default=0)
 ap.add_argument("--frames-in-flight", type=int, default=0)
 ap.add_argument("--waves", type=int, default=0)
+ap.add_argument("--split", type=int, default=-1, help="rt_set_box_test_split: level-0 traces of at least this many rays run as two launches")
 ap.add_argument("--cost-order", action="store_true", help="tiles in order of falling cost, measured by a counter frame (rt_set_tile_list)")
 ap.add_argument("--fast", action="store_true", help="the FAST build of the kernels (rt_set_arithmetic)")
 ap.add_argument("--tile-order", type=int, default=-1)
@@ -50,6 +51,8 @@ print(f"scene {a.scene} size {a.size}: built in {time.time()-t:.2f}s, depth {sce
 with rt.Context(0) as ctx:
     if a.waves:
         ctx.set_trace_waves(a.waves)
+    if a.split >= 0:
+        ctx.set_box_test_split(a.split)
     if a.fast:
         ctx.set_arithmetic(True)
     if a.tile_order >= 0:
