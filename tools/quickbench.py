@@ -123,7 +123,11 @@ with rt.Context(0) as ctx:
     print(f"host time inside rt_render: {issue/a.steps*1e3:.3f} ms per frame")
     ctx.sync()
     wall = (time.perf_counter() - t0) / a.steps * 1e3
-    total, st, n = ctx.timing_read_stages()
+    try:
+        total, st, n = ctx.timing_read_stages()
+    except rt.RtError:  # no stage events (an experiment path that does not record them)
+        total, st, n = 0.0, [0.0] * 4, 1
+    n = max(n, 1)
     print(f"rays/frame {rays} (primary {c['primary']} shadow {c['shadow']} secondary {c['secondary']}), node/ray {c['node']/rays:.1f} tri/ray {c['tri']/rays:.1f}")
     print(f"frame {total/n:.3f} ms  | primary-trace {st[0]/n:.3f}  shade {st[1]/n:.3f}  shadow-trace {st[2]/n:.3f}  rest {st[3]/n:.3f}  | "
           f"wall {wall:.3f} ms/frame = {rays/a.stride/wall/1e3:.1f} Mrays/s", flush=True)
