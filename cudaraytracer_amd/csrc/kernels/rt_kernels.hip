@@ -740,10 +740,9 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     // RT_QUAD_ONE: the child is a leaf and its half holds only itself, RT_QUAD_NONE: no such child
                     const unsigned axP = RT_REF_AXIS(cur), axA = __float_as_uint(A1.w), axB = __float_as_uint(B1.w);
                     const unsigned long long sx = B(inv.x < 0.0f), sy = B(inv.y < 0.0f), sz = B(inv.z < 0.0f);
-                    // (whether a shadow ray is blocked does not depend on the order of its tests: it takes the four as stored)
-                    const unsigned long long mNP = ANY ? 0ull : (B(axP == 0u) & sx) | (B(axP == 1u) & sy) | (B(axP == 2u) & sz);
-                    const unsigned long long mNA = ANY ? 0ull : (B(axA == 0u) & sx) | (B(axA == 1u) & sy) | (B(axA == 2u) & sz);
-                    const unsigned long long mNB = ANY ? 0ull : (B(axB == 0u) & sx) | (B(axB == 1u) & sy) | (B(axB == 2u) & sz);
+                    const unsigned long long mNP = (B(axP == 0u) & sx) | (B(axP == 1u) & sy) | (B(axP == 2u) & sz);
+                    const unsigned long long mNA = (B(axA == 0u) & sx) | (B(axA == 1u) & sy) | (B(axA == 2u) & sz);
+                    const unsigned long long mNB = (B(axB == 0u) & sx) | (B(axB == 1u) & sy) | (B(axB == 2u) & sz);
                     const unsigned long long hA0 = B(ta0 <= fa0) & B(fa0 > 0.0f) & B(ta0 < tMax);
                     const unsigned long long hA1 = B(ta1 <= fa1) & B(fa1 > 0.0f) & B(ta1 < tMax) & B(axA < RT_QUAD_ONE);
                     const unsigned long long hB0 = B(tb0 <= fb0) & B(fb0 > 0.0f) & B(tb0 < tMax) & B(axB < RT_QUAD_NONE);
