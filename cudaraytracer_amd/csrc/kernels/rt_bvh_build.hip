@@ -362,6 +362,8 @@ __global__ void quadKernel(const uint32_t* __restrict__ pairs, uint32_t pairBase
 #pragma unroll
         for (int k = 0; k < 8; ++k) out[k] = rec[k];
         axisWord = RT_QUAD_ONE;
+    } else if (RT_REF_PAIR_UNITS(ref) - pairBase >= pairCnt) {
+        axisWord = RT_QUAD_NONE;  // a reference that leaves the tree (the packer lets none through): nothing to visit
     } else {
         const uint32_t* child = pairs + (size_t)(RT_REF_PAIR_UNITS(ref) - pairBase) * 16;
 #pragma unroll

@@ -210,6 +210,11 @@ int treeDepth(const RtLinearNode* nodes, int nodeCnt, int primCnt, int* maxLeafP
             todo.push_back({n.offset, it.level + 1});
         }
     }
+    if (visited != (size_t)nodeCnt) {
+        // the sizes of the device-side node arrays follow from the count
+        *err = "BVH node array holds nodes the root does not reach";
+        return -1;
+    }
     return depth;
 }
 

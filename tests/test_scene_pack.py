@@ -125,6 +125,13 @@ def test_malformed_scenes_are_rejected(rtlib):
         d.nodes[inner].offset = d.nodeCnt + 5
         expect_error(rtlib, s.desc, RT_ERR_INVALID, "")
         d.nodes[inner].offset = keep
+    # nodes the root does not reach: an interior node of the mesh turned into a leaf strands its subtree
+    inner = next((i for i in range(mesh.nodeCnt) if mesh.nodes[i].primCnt == 0), None)
+    if inner is not None:
+        keep = (mesh.nodes[inner].offset, mesh.nodes[inner].primCnt)
+        mesh.nodes[inner].offset, mesh.nodes[inner].primCnt = 0, 1
+        expect_error(rtlib, s.desc, RT_ERR_INVALID, "does not reach")
+        mesh.nodes[inner].offset, mesh.nodes[inner].primCnt = keep
     # shape naming a mesh that is not there
     ms = next(i for i in range(d.shapeCnt) if d.shapes[i].kind == 1)
     keep = d.shapes[ms].meshIdx
