@@ -101,7 +101,9 @@ typedef struct RtLight {
 
 /* cudaTracer/Mesh.cuh:17-26.  `triangles` are in mesh-BVH leaf order
  * (cudaTracer/CudaMesh.h:60-63); `transformInverse` is row-major, row-vector
- * convention (cudaTracer/Mat.cuh:127-149). */
+ * convention (cudaTracer/Mat.cuh:127-149).  `nodes` is the tree as
+ * cudaTracer/BVH.h:152-180 flattens it: `nodeCnt` entries, all of them reached
+ * from entry 0 (an array with stray entries is rejected). */
 typedef struct RtMesh {
     int32_t triangleCnt;
     const RtTriangle* triangles;
