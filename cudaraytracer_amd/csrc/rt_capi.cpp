@@ -206,6 +206,15 @@ int treeDepth(const RtLinearNode* nodes, int nodeCnt, int primCnt, int* maxLeafP
                 *err = "BVH interior node with bad axis";
                 return -1;
             }
+            // The walk over quads (rt_device_format.h) tests grandchildren without their parents: a node's box must hold
+            // its children's boxes, as the exact union the reference's builder makes it (cudaTracer/BVH.h:90-96) does.
+            if (n.offset > it.idx && n.offset < nodeCnt)
+                for (int child : {it.idx + 1, (int)n.offset})
+                    for (int k = 0; k < 3; ++k)
+                        if (!(n.bbmin[k] <= nodes[child].bbmin[k] && nodes[child].bbmax[k] <= n.bbmax[k])) {
+                            *err = "BVH node whose box does not contain its child's box";
+                            return -1;
+                        }
             todo.push_back({it.idx + 1, it.level + 1});
             todo.push_back({n.offset, it.level + 1});
         }

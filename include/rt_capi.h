@@ -103,7 +103,9 @@ typedef struct RtLight {
  * (cudaTracer/CudaMesh.h:60-63); `transformInverse` is row-major, row-vector
  * convention (cudaTracer/Mat.cuh:127-149).  `nodes` is the tree as
  * cudaTracer/BVH.h:152-180 flattens it: `nodeCnt` entries, all of them reached
- * from entry 0 (an array with stray entries is rejected). */
+ * from entry 0 (an array with stray entries is rejected), and an interior
+ * entry's box holds the boxes of its two children, as the union that builder
+ * forms does (the trace kernels test grandchildren without their parents). */
 typedef struct RtMesh {
     int32_t triangleCnt;
     const RtTriangle* triangles;

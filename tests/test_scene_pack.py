@@ -132,6 +132,13 @@ def test_malformed_scenes_are_rejected(rtlib):
         mesh.nodes[inner].offset, mesh.nodes[inner].primCnt = 0, 1
         expect_error(rtlib, s.desc, RT_ERR_INVALID, "does not reach")
         mesh.nodes[inner].offset, mesh.nodes[inner].primCnt = keep
+    # a child box that sticks out of its parent's
+    if inner is not None:
+        child = inner + 1
+        keep = mesh.nodes[child].bbmax[0]
+        mesh.nodes[child].bbmax[0] = mesh.nodes[inner].bbmax[0] + 1.0
+        expect_error(rtlib, s.desc, RT_ERR_INVALID, "does not contain")
+        mesh.nodes[child].bbmax[0] = keep
     # shape naming a mesh that is not there
     ms = next(i for i in range(d.shapeCnt) if d.shapes[i].kind == 1)
     keep = d.shapes[ms].meshIdx
