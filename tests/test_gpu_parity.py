@@ -209,10 +209,42 @@ def test_deep_stack_spills_to_global_memory(gpu_ctx, oracle):
     gpu_ctx.set_lds_stack(1)
     try:
         rgba, keys, cnt = gpu_ctx.render_frame(scene, want_keys=True, want_counters=True)
+        # the plain build walks quads (up to three pushes per node step) where the counter build walks pairs
+        rgba2, keys2, _ = gpu_ctx.render_frame(scene, want_keys=True)
     finally:
         gpu_ctx.set_lds_stack(8)
     assert_parity(rgba, keys, ref_rgba, ref_keys)
     assert cnt == ref_cnt
+    assert np.array_equal(keys, keys2)
+    assert np.array_equal(rgba, rgba2, equal_nan=True)
+
+
+def test_overlapping_boxes_fill_the_stack_of_the_quad_walk(gpu_ctx, oracle):
+    """Triangles stacked along the view direction in a deep tree whose boxes all hold the centre rays: every box test
+    passes, so the walk over quads keeps three entries waiting per step, well past the LDS ring."""
+    import hand_scenes as hs
+    from test_gpu_fuzz import bvh_of
+
+    import cudaraytracer_amd
+
+    rtlib = cudaraytracer_amd.load()
+    n = 3000
+    tris = []
+    for k in range(n):
+        z = 4.0 + 0.01 * k
+        s = 3.0 + 0.001 * (k % 7)
+        tris.append(hs.tri((-s, -s, z), (-s, 2 * s, z), (2 * s, -s, z)) if k % 3 else hs.tri((-s, -s, z), (2 * s, -s, z), (-s, 2 * s, z)))
+    tris, spec = bvh_of(rtlib, tris, 0, 1, 1)  # median cut down to single triangles: depth 12, every box around the axis
+    scene = hs.Scene(17, 13, [hs.Mesh(tris, nodes=spec)], lights=[((0, 0, 0), (1, 1, 1), 5.0), ((1, 2, 0), (1, 1, 1), 3.0)])
+    ref_rgba, ref_keys = scene.render_oracle(oracle)
+    gpu_ctx.set_lds_stack(2)
+    try:
+        rgba, keys = scene.render_gpu(gpu_ctx)
+    finally:
+        gpu_ctx.set_lds_stack(8)
+    assert (ref_keys[..., 0] == 0).mean() > 0.3
+    assert np.array_equal(keys, ref_keys)
+    assert np.array_equal(rgba, ref_rgba, equal_nan=True)
 
 
 # ---- tile shards, scene hand-over, lights ------------------------------------------------------
