@@ -352,18 +352,18 @@ __global__ void quadKernel(const uint32_t* __restrict__ pairs, uint32_t pairBase
     const uint32_t i = t >> 1, h = t & 1u;
     const uint32_t* rec = pairs + (size_t)i * 16 + h * 8;
     const uint32_t ref = rec[6];
+    // records that are not there: a box of NaNs passes no box test, whatever the ray
     uint32_t out[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) out[k] = 0u;
-    uint32_t axisWord;
+    for (int k = 0; k < 16; ++k) out[k] = (k & 7) < 6 ? 0x7fc00000u : 0u;
+    uint32_t axisWord = 0u;  // one-hot split axis of the record whose children the half holds; 0: fewer than two records
     if (i == 0u && h == 1u) {
-        axisWord = RT_QUAD_NONE;  // the padding beside the tree's root record
+        // the padding beside the tree's root record: an empty half
     } else if (RT_REF_IS_LEAF(ref)) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) out[k] = rec[k];
-        axisWord = RT_QUAD_ONE;
     } else if (RT_REF_PAIR_UNITS(ref) - pairBase >= pairCnt) {
-        axisWord = RT_QUAD_NONE;  // a reference that leaves the tree (the packer lets none through): nothing to visit
+        // a reference that leaves the tree (the packer lets none through): nothing to visit
     } else {
         const uint32_t* child = pairs + (size_t)(RT_REF_PAIR_UNITS(ref) - pairBase) * 16;
 #pragma unroll
@@ -373,7 +373,7 @@ __global__ void quadKernel(const uint32_t* __restrict__ pairs, uint32_t pairBase
             const uint32_t r = out[k];
             if (!RT_REF_IS_LEAF(r)) out[k] = (r & 0x60000000u) | (RT_REF_PAIR_UNITS(r) - pairBase + quadBase);
         }
-        axisWord = RT_REF_AXIS(ref);
+        axisWord = 1u << RT_REF_AXIS(ref);
     }
     out[7] = axisWord;
     uint4* dst = reinterpret_cast<uint4*>(quads + (size_t)(quadBase + i) * 32 + h * 16);

@@ -455,6 +455,8 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     int sp = 0, lo = 0;  // stack entries [lo, sp) are in the LDS ring, [0, lo) in global memory
     int hShape = -1, hTri = -1;
     float hu = 0.0f, hv = 0.0f;
+    unsigned sgn = 0;  // kQuad: bit a set = the ray runs towards smaller coordinates along axis a, in the space it is walked in
+    auto signsOf = [](const V3 r) { return (r.x < 0.0f ? 1u : 0u) | (r.y < 0.0f ? 2u : 0u) | (r.z < 0.0f ? 4u : 0u); };
     // Splitting shadow rays.  A launch ends with its longest rays: one ray in a thousand makes ten times the average
     // number of tests, and when such a ray starts late, the whole machine waits for one lane.  Whether a shadow ray is
     // blocked does not depend on the order of its tests, so once the queue is dry, lanes without a ray take over the
@@ -580,7 +582,10 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                         tMax = 3.402823466e+38f;
                     }
                 }
-                if (item >= 0 && valid) inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                if (item >= 0 && valid) {
+                    inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    if (kQuad) sgn = signsOf(inv);
+                }
                 if (item < 0) {
                     // nothing to walk
                 } else if (kDefer && valid && special(inv)) {
@@ -736,17 +741,15 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     float ta0, fa0, ta1, fa1, tb0, fb0, tb1, fb1;
                     boxPairMinMax(A0, A1, A2, A3, o, inv, ta0, fa0, ta1, fa1);
                     boxPairMinMax(B0, B1, B2, B3, o, inv, tb0, fb0, tb1, fb1);
-                    // split axes: of the node (orders the halves) and of its two children (order inside a half);
-                    // RT_QUAD_ONE: the child is a leaf and its half holds only itself, RT_QUAD_NONE: no such child
-                    const unsigned axP = RT_REF_AXIS(cur), axA = __float_as_uint(A1.w), axB = __float_as_uint(B1.w);
-                    const unsigned long long sx = B(inv.x < 0.0f), sy = B(inv.y < 0.0f), sz = B(inv.z < 0.0f);
-                    const unsigned long long mNP = (B(axP == 0u) & sx) | (B(axP == 1u) & sy) | (B(axP == 2u) & sz);
-                    const unsigned long long mNA = (B(axA == 0u) & sx) | (B(axA == 1u) & sy) | (B(axA == 2u) & sz);
-                    const unsigned long long mNB = (B(axB == 0u) & sx) | (B(axB == 1u) & sy) | (B(axB == 2u) & sz);
+                    // Split axes as one-hot words: of the node (orders the halves) and of its two children (order inside a
+                    // half; 0 where a half holds fewer than two records).  Records that are not there have NaN boxes, which
+                    // pass no test.  The root's pseudo reference has axis 3: its bit meets none of the ray's three.
+                    const unsigned ohP = 1u << RT_REF_AXIS(cur), ohA = __float_as_uint(A1.w), ohB = __float_as_uint(B1.w);
+                    const unsigned long long mNP = B((sgn & ohP) != 0u), mNA = B((sgn & ohA) != 0u), mNB = B((sgn & ohB) != 0u);
                     const unsigned long long hA0 = B(ta0 <= fa0) & B(fa0 > 0.0f) & B(ta0 < tMax);
-                    const unsigned long long hA1 = B(ta1 <= fa1) & B(fa1 > 0.0f) & B(ta1 < tMax) & B(axA < RT_QUAD_ONE);
-                    const unsigned long long hB0 = B(tb0 <= fb0) & B(fb0 > 0.0f) & B(tb0 < tMax) & B(axB < RT_QUAD_NONE);
-                    const unsigned long long hB1 = B(tb1 <= fb1) & B(fb1 > 0.0f) & B(tb1 < tMax) & B(axB < RT_QUAD_ONE);
+                    const unsigned long long hA1 = B(ta1 <= fa1) & B(fa1 > 0.0f) & B(ta1 < tMax);
+                    const unsigned long long hB0 = B(tb0 <= fb0) & B(fb0 > 0.0f) & B(tb0 < tMax);
+                    const unsigned long long hB1 = B(tb1 <= fb1) & B(fb1 > 0.0f) & B(tb1 < tMax);
                     // cudaTracer/Mesh.cuh:155-161 twice over: inside a half the record on the ray's side of the child's
                     // split comes first, and the half on the ray's side of the node's split comes first
                     const bool negA = __builtin_amdgcn_inverse_ballot_w64(mNA), negB = __builtin_amdgcn_inverse_ballot_w64(mNB);
@@ -900,6 +903,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     d = mk((wd.x * m0.x + wd.y * m1.x) + wd.z * m2.x, (wd.x * m0.y + wd.y * m1.y) + wd.z * m2.y,
                            (wd.x * m0.z + wd.y * m1.z) + wd.z * m2.z);
                     inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                    if (kQuad) sgn = signsOf(inv);
                     // cudaTracer/Mesh.cuh:137-138: root box test, or all triangles in order without a BVH
                     cur = useMeshBvhs ? (kQuad ? P.meshRootQuad[s.meshIdx] : m->rootRef) : (TAG_TRI | m->recordBase);
                     end = m->recordBase + (unsigned)m->triangleCnt;
@@ -925,6 +929,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                         o = mk(__uint_as_float(e0.x), __uint_as_float(e0.y), __uint_as_float(e1.x));
                         d = mk(__uint_as_float(e1.y), __uint_as_float(e2.x), __uint_as_float(e2.y));
                         inv = mk(__uint_as_float(e3.x), __uint_as_float(e3.y), __uint_as_float(e4.x));
+                        if (kQuad) sgn = signsOf(inv);
                         floorAt = (int)e4.y;
                             end = c.y;
                         cur = (c.x & IDX_MASK) < c.y ? c.x : CUR_POP;
@@ -983,6 +988,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                         tMax = A.w;
                         d = mk(B.x, B.y, B.z);
                         inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                        if (kQuad) sgn = signsOf(inv);
                         hShape = -1;
                         sp = 0;
                         lo = 0;

@@ -28,10 +28,10 @@
 // QUADS.  Beside the blob, a scene holds one 128-byte QUAD record per sibling pair (built on the device when the scene
 // is uploaded or adopted; rtk_build_quads): the pair's two records each replaced by the pair of ITS children, so that
 // one fetch brings the boxes of a node's four grandchildren.  Half h (64 bytes, laid out like a pair) is the child
-// pair of the pair's record h with that record's split axis in the spare word of its first record; if record h is a
-// leaf, the half is the record itself plus an empty one and the axis word is RT_QUAD_ONE; for the padding beside a
-// root record the half is empty and the word is RT_QUAD_NONE.  Interior references inside quads name quads (128-byte
-// units from the start of the quad array).  The launches with the min / max box test walk quads: a box that a ray
+// pair of the pair's record h with 1 << (that record's split axis) in the spare word of its first record; if record h
+// is a leaf, the half is the record itself plus an empty one and the word is 0; for the padding beside a root record
+// the half is empty.  An empty record has a box of NaNs, which passes no box test.  Interior references inside quads
+// name quads (128-byte units from the start of the quad array).  The launches with the min / max box test walk quads: a box that a ray
 // hits lies inside its parent's box, so the parent's own test cannot change which leaves are reached, and the four
 // grandchildren are visited in the order the two levels of the binary walk would visit them.
 //
@@ -73,8 +73,6 @@
 #define RT_REF_AXIS(r) (((r) >> 29) & 3u)
 #define RT_REF_ROOT_AXIS 3u
 #define RT_REF_PAIR_UNITS(r) ((r)&0x1fffffffu) /* 64-byte units from the blob start */
-#define RT_QUAD_ONE 3u  /* axis word of a quad half that holds one record (a leaf child) */
-#define RT_QUAD_NONE 4u /* ... that holds none (beside a root record) */
 
 struct BlobHeader {
     uint32_t magic;
