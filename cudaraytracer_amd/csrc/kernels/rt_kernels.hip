@@ -293,6 +293,10 @@ __device__ __forceinline__ void shadowRay(const FrameParams& P, unsigned k, int 
 //   CUR_POP               take the next entry from the traversal stack
 //   CUR_DONE              the ray is finished (also the value of a lane without a ray)
 constexpr unsigned CUR_POP = 0xFFFFFFFFu, CUR_DONE = 0xFFFFFFFEu;
+// Population count of a lane mask from its two halves: a 64-bit count would be compared as a 64-bit number, for which
+// the scalar unit has no ordering compare, and the comparison of two wave-uniform numbers would go to the vector unit.
+__device__ __forceinline__ int pop64(unsigned long long m) { return __builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32)); }
+
 constexpr unsigned TAG_TRI = 0x80000000u, TAG_SHAPE = 0xC0000000u, IDX_MASK = 0x3FFFFFFFu;
 constexpr unsigned STACK_MESH_EXIT = 0xFFFFFFFDu;  // stack marker: the mesh walk is over, restore the world-space ray
 constexpr int HIT_PENDING = -3;                    // hShape while the hit mesh is still being walked
@@ -530,7 +534,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
         // ---- hand new rays to lanes without one ----------------------------
         const unsigned long long idle = __ballot(item < 0);
         if (idle != 0ull && !exhausted) {
-            const unsigned want = (unsigned)__popcll(idle);
+            const unsigned want = (unsigned)pop64(idle);
             const unsigned rank = laneRank(idle);
             unsigned given = 0;
             while (given < want) {
@@ -622,10 +626,10 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
         while (true) {
             const unsigned long long nodeMask = __ballot((int)cur >= 0);
             const unsigned long long triMask = __ballot((cur >> 30) == 2u);
-            const int nTri = __popcll(triMask);
+            const int nTri = pop64(triMask);
             const bool triPhase = nTri != 0 && (nTri >= RT_TRI_LANES || nodeMask == 0ull);
             if (COUNT) {
-                const unsigned nb = (unsigned)__popcll(__ballot(cur != CUR_DONE));
+                const unsigned nb = (unsigned)pop64(__ballot(cur != CUR_DONE));
                 wSteps++;
                 wBusyLanes += nb;
                 if (exhausted) {
@@ -729,7 +733,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                 // ========================= node step ==========================
                 if (COUNT) {
                     wNodeSteps++;
-                    wNodeLanes += __popcll(nodeMask);
+                    wNodeLanes += pop64(nodeMask);
                 }
                 if (kQuad && (int)cur >= 0) {
                     // One 128-byte fetch: the child pairs of both children of the node (halves A and B).  The children's
@@ -961,7 +965,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                 const bool giver = item >= 0 && cur != CUR_DONE && sp > floorAt;
                 const unsigned long long takeM = __ballot(taker), giveM = __ballot(giver);
                 if (takeM != 0ull && giveM != 0ull) {
-                    unsigned n = (unsigned)__popcll(takeM) < (unsigned)__popcll(giveM) ? (unsigned)__popcll(takeM) : (unsigned)__popcll(giveM);
+                    unsigned n = (unsigned)pop64(takeM) < (unsigned)pop64(giveM) ? (unsigned)pop64(takeM) : (unsigned)pop64(giveM);
                     n = n < (unsigned)kTriPart ? n : (unsigned)kTriPart;
                     const unsigned gr = laneRank(giveM), tr = laneRank(takeM);
                     if (giver && gr < n) {
@@ -1004,7 +1008,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
             // keep going while most lanes still work; once the queue is dry, until all are done
             const unsigned long long busy = __ballot(cur != CUR_DONE);
             if (busy == 0ull) break;
-            if (!exhausted && __popcll(busy) <= kWave - RT_REFILL_LANES && __ballot(item >= 0) != busy) break;
+            if (!exhausted && pop64(busy) <= kWave - RT_REFILL_LANES && __ballot(item >= 0) != busy) break;
         }
 
         // ---- finished lanes publish their result and give up their ray -----
@@ -1297,8 +1301,8 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams P, const in
         const unsigned long long m1 = __ballot(want >= 1), m2 = __ballot(want == 2);  // want is 0, 1 or 2
         const unsigned wave = threadIdx.x >> 6;
         if ((threadIdx.x & 63u) == 0u) {
-            s_count[wave] = (unsigned)__popcll(dmask);
-            s_want[wave] = (unsigned)__popcll(m1) + (unsigned)__popcll(m2);
+            s_count[wave] = (unsigned)pop64(dmask);
+            s_want[wave] = (unsigned)pop64(m1) + (unsigned)pop64(m2);
         }
         __syncthreads();
         if (threadIdx.x == 0) {
