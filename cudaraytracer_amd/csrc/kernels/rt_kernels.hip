@@ -422,8 +422,14 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     const unsigned first = (ANY || fromList) ? 0u : P.ctl[CTL_LEVEL_START + level];
     unsigned* const queues = P.ctl + RT_QUEUE_WORD((rescue ? 2 : 0) + (ANY ? 1 : 0), 0);
     const unsigned chunks = (total + kChunk - 1) / kChunk;
-    // true if the min / max box test may differ from the literal one for a ray with this reciprocal direction
-    auto special = [](const V3 r) { return __builtin_isinf(r.x) || __builtin_isinf(r.y) || __builtin_isinf(r.z); };
+    // True if the min / max box test may differ from the literal one for a ray with this reciprocal direction and
+    // origin: an infinite component of the former (0 * inf = NaN for a ray in a box face), or a NaN in either (min / max
+    // drop a NaN operand where the reference's chain of comparisons keeps it and misses).
+    auto special = [](const V3 r, const V3 from) {
+        const float big = __builtin_huge_valf();
+        return !(__builtin_fabsf(r.x) < big) || !(__builtin_fabsf(r.y) < big) || !(__builtin_fabsf(r.z) < big) || from.x != from.x ||
+               from.y != from.y || from.z != from.z;
+    };
     // With little work, only as many wavefronts take part as get P.waveChunks chunks each.  One chunk each spreads
     // the rays over the most wavefronts (shortest launch when nothing else runs); several make a wavefront refill
     // its lanes instead of running a single chunk dry, and leave slots free for the kernels of other frames in flight.
@@ -592,7 +598,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                 }
                 if (item < 0) {
                     // nothing to walk
-                } else if (kDefer && valid && special(inv)) {
+                } else if (kDefer && valid && special(inv, o)) {
                     hShape = HIT_DEFERRED;  // published as such below; cur stays CUR_DONE
                 } else if (valid) {
                     if (COUNT) {
@@ -911,7 +917,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     // cudaTracer/Mesh.cuh:137-138: root box test, or all triangles in order without a BVH
                     cur = useMeshBvhs ? (kQuad ? P.meshRootQuad[s.meshIdx] : m->rootRef) : (TAG_TRI | m->recordBase);
                     end = m->recordBase + (unsigned)m->triangleCnt;
-                    if (kDefer && special(inv)) {
+                    if (kDefer && special(inv, o)) {
                         // in this mesh's space the ray runs along an axis plane: the whole ray goes to the rescue launch
                         hShape = HIT_DEFERRED;
                         cur = CUR_DONE;

@@ -54,3 +54,17 @@ def test_ray_along_an_axis_plane_of_a_rotated_mesh(gpu_ctx, oracle):
     assert (ref_keys[..., 0] == 0).sum() >= 12  # the triangle fills the frame but for a corner
     assert np.array_equal(keys, ref_keys)
     assert np.array_equal(rgba, ref_rgba, equal_nan=True)
+
+
+def test_ray_with_a_nan_in_its_origin_misses_like_the_reference(gpu_ctx, oracle):
+    """A NaN in one coordinate of the origin makes that axis' plane distances NaN.  The reference's chain of comparisons
+    (cudaTracer/BoundingBox.cuh:115-139) then never passes a box; a min / max form would drop the NaN operands and test the
+    other two axes.  Such rays must go the literal way: every pixel as the oracle has it (the background)."""
+    big = ((-30, -30, 5), (-30, 60, 5), (60, -30, 5))
+    scene = hs.Scene(9, 7, [hs.Mesh([hs.tri(*big)])], spheres=[((0, 0, 8), 2.0, hs.DIFFUSE, 1.3, (1, 1, 1))], lights=hs.LIGHT_AT_CAMERA,
+                     origin=(float("nan"), 0.0, 0.0))
+    ref_rgba, ref_keys = scene.render_oracle(oracle)
+    rgba, keys = scene.render_gpu(gpu_ctx)
+    assert (ref_keys[..., 0] == -1).all()  # what the reference's arithmetic makes of it: nothing is hit
+    assert np.array_equal(keys, ref_keys)
+    assert np.array_equal(rgba, ref_rgba, equal_nan=True)
