@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     int sp = 0, lo = 0;  // stack entries [lo, sp) are in the LDS ring, [0, lo) in global memory
     int hShape = -1, hTri = -1;
     float hu = 0.0f, hv = 0.0f;
-    unsigned sgn = 0;  // kQuad: bit a set = the ray runs towards smaller coordinates along axis a, in the space it is walked in
+    unsigned sgn = 0;  // bit a set = the ray runs towards smaller coordinates along axis a, in the space it is walked in
     auto signsOf = [](const V3 r) { return (r.x < 0.0f ? 1u : 0u) | (r.y < 0.0f ? 2u : 0u) | (r.z < 0.0f ? 4u : 0u); };
     // Splitting shadow rays.  A launch ends with its longest rays: one ray in a thousand makes ten times the average
     // number of tests, and when such a ray starts late, the whole machine waits for one lane.  Whether a shadow ray is
@@ -594,7 +594,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                 }
                 if (item >= 0 && valid) {
                     inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                    if (kQuad) sgn = signsOf(inv);
+                    sgn = signsOf(inv);
                 }
                 if (item < 0) {
                     // nothing to walk
@@ -852,7 +852,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     const unsigned axis = RT_REF_AXIS(cur);
                     // cudaTracer/Mesh.cuh:155-161: with a negative direction along the split axis the
                     // second child is nearer; the other one waits on the stack.  A root record has no sibling.
-                    const unsigned long long mNeg = (B(axis == 0u) & B(inv.x < 0.0f)) | (B(axis == 1u) & B(inv.y < 0.0f)) | (B(axis == 2u) & B(inv.z < 0.0f));
+                    const unsigned long long mNeg = B(((sgn >> axis) & 1u) != 0u);  // (the root's axis 3 meets no sign bit)
                     const unsigned long long mSingle = B(axis == (unsigned)RT_REF_ROOT_AXIS);
                     const bool single = __builtin_amdgcn_inverse_ballot_w64(mSingle);
                     const bool negAxis = __builtin_amdgcn_inverse_ballot_w64(mNeg);
@@ -913,7 +913,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     d = mk((wd.x * m0.x + wd.y * m1.x) + wd.z * m2.x, (wd.x * m0.y + wd.y * m1.y) + wd.z * m2.y,
                            (wd.x * m0.z + wd.y * m1.z) + wd.z * m2.z);
                     inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                    if (kQuad) sgn = signsOf(inv);
+                    sgn = signsOf(inv);
                     // cudaTracer/Mesh.cuh:137-138: root box test, or all triangles in order without a BVH
                     cur = useMeshBvhs ? (kQuad ? P.meshRootQuad[s.meshIdx] : m->rootRef) : (TAG_TRI | m->recordBase);
                     end = m->recordBase + (unsigned)m->triangleCnt;
@@ -939,7 +939,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                         o = mk(__uint_as_float(e0.x), __uint_as_float(e0.y), __uint_as_float(e1.x));
                         d = mk(__uint_as_float(e1.y), __uint_as_float(e2.x), __uint_as_float(e2.y));
                         inv = mk(__uint_as_float(e3.x), __uint_as_float(e3.y), __uint_as_float(e4.x));
-                        if (kQuad) sgn = signsOf(inv);
+                        sgn = signsOf(inv);
                         floorAt = (int)e4.y;
                             end = c.y;
                         cur = (c.x & IDX_MASK) < c.y ? c.x : CUR_POP;
@@ -998,7 +998,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                         tMax = A.w;
                         d = mk(B.x, B.y, B.z);
                         inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-                        if (kQuad) sgn = signsOf(inv);
+                        sgn = signsOf(inv);
                         hShape = -1;
                         sp = 0;
                         lo = 0;
