@@ -11,10 +11,10 @@ t = rank, rank+N, ... of the same frame, and the tiles are gathered to rank 0
 inside the timed region (strong scaling: the frame is fixed, the work per GPU
 shrinks).  Rank 0 prints ONE JSON line.
 
-`value` is measured with the EXACT build of the kernels (bit-identical to the
-reference's formulas) and frames in flight; the same line carries the strictly
-in-order figure, the FAST build, the other workloads of the scope table, the
-roofline of the dominant kernel and the CPU baseline.
+`value` is measured with frames in flight; the same line carries the strictly
+in-order figure, the figure a process with HIP's default four hardware queues
+gets, the other workloads of the scope table, the roofline of the dominant
+kernel and the CPU baseline.
 """
 import os
 
@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--tile-balance", choices=("cost", "interleaved"), default="cost",
                     help="N > 1: tiles per GPU by measured cost (equal box + triangle tests per GPU) or tile t on GPU t %% N")
-    ap.add_argument("--no-others", action="store_true", help="skip the other workloads and the FAST build (headline only)")
+    ap.add_argument("--no-others", action="store_true", help="skip the other workloads and the default-hardware-queues run (headline only)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="consecutive frames that may overlap on a GPU (1 = strictly in order, at most 16; default 12)")
     return ap.parse_args()
@@ -410,7 +410,7 @@ def main():
             out = [float(x) for x in t.tolist()]
         return out[:5], out[5]
 
-    # ================= the timed region (EXACT build) =================
+    # ================= the timed region =================
     elapsed, issue_s, in_flight_stage = timed_region(args.steps, args.warmup)
     alone_stage, alone_wall = alone() if nf > 1 else (in_flight_stage, elapsed / args.steps * 1e3)
 
@@ -429,44 +429,10 @@ def main():
         differing = int(((a != b) & ~(torch.isnan(a) & torch.isnan(b))).any(dim=2).sum().item())
         gather_check = "identical to the frame rendered whole on GPU 0" if differing == 0 else f"{differing} pixels differ from the frame rendered whole on GPU 0"
 
-    # ================= the FAST build on the same workload (untimed for `value`) =================
-    fast = None
-    if not args.no_others:
-        exact_keys = torch.zeros((h, w, 4), dtype=torch.int32, device=dev)
-        fast_keys = torch.zeros((h, w, 4), dtype=torch.int32, device=dev)
-        exact_frame = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
-        ctx.set_frames_in_flight(1)
-        ctx.render(dscene, opts, camera_ref, exact_frame.data_ptr(), pitch, exact_keys.data_ptr(), None, *shard)
-        ctx.sync()
-        ctx.set_arithmetic(True)
-        ctx.render(dscene, opts, camera_ref, surfaces[0].data_ptr(), pitch, fast_keys.data_ptr(), None, *shard)
-        ctx.sync()
-        torch.cuda.synchronize(dev)
-        f_elapsed, _, _ = timed_region(max(args.steps // 2, 10), 2)
-        f_steps = max(args.steps // 2, 10)
-        f_alone, f_alone_wall = alone()
-        ctx.set_arithmetic(False)
-        if rank == 0:
-            a, b = surfaces[0], exact_frame  # the last fast frame and the exact frame
-            same_key = (exact_keys == fast_keys).all(dim=2)
-            both_nan = torch.isnan(a) & torch.isnan(b)
-            rel = ((a - b).abs() / b.abs().clamp_min(1e-12)).masked_fill(both_nan, 0.0)
-            lsb = ((a * 256).nan_to_num(0.0).clamp(0, 255).floor() - (b * 256).nan_to_num(0.0).clamp(0, 255).floor()).abs()
-            ok = ((rel <= 1e-4) | (lsb <= 1)).all(dim=2)
-            fast = {"value": rays * f_steps / f_elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": f_elapsed / f_steps * 1e3,
-                    "in_order_ms_per_frame": f_alone[0], "in_order_Mrays_per_s": rays / f_alone_wall / 1e3,
-                    "hit_key_agreement_with_exact_build": float(same_key.float().mean().item()) if world == 1 else None,
-                    "radiance_within_tolerance_fraction": float(ok.float().mean().item()) if world == 1 else None,
-                    "note": "rt_set_arithmetic(FAST): shading contracted to fused multiply-adds, fp32 texture weights, the min / max box "
-                            "test for every ray (no second launch for rays along axis planes); everything else that decides which "
-                            "primitive a ray hits keeps the exact arithmetic. Tolerance: hit keys "
-                            ">= 99.99 %, radiance 1e-4 relative or one 8-bit step (tests/test_gpu_fast_build.py holds it against the oracle)"}
-        del exact_keys, fast_keys, exact_frame
-
     # ================= other workloads of the scope table (untimed for `value`, one GPU) =================
     others = []
     if not args.no_others and not multi:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
         import tempfile
 
         import synth_assets
@@ -538,7 +504,7 @@ def main():
                                       "tight-bounds BVH cut by the binned surface-area heuristic, leaves <= 8 triangles (rt_mesh_bvh_build's rule; "
                                       "the reference's median-cut tree is under other_workloads); " if args.bvh == "sah" else
                                       "tight-bounds BVH, the reference's median cut, leaves <= 10; ") +
-                                   "EXACT build of the kernels (bit-identical to the reference's formulas)",
+                                   "fp32 arithmetic in the reference's operation order, no fused multiply-adds (bit-identical to the reference's formulas)",
                        "rays_per_frame": rays, "primary": cnt["primary"], "shadow": cnt["shadow"],
                        "tile_sharding": ("single GPU" if not multi else
                                          f"8x8 tiles, per-GPU lists of equal measured cost (box + triangle tests of a counter frame), gathered to GPU0 each frame"
@@ -555,7 +521,6 @@ def main():
             "kernel_ms": {"frame": frame_ms, "trace_closest": closest_ms, "shade": shade_ms, "trace_shadow": shadow_ms, "rest": rest_ms,
                           "note": "launches running alone (one frame in flight), HIP events on the launch stream, measured after the timed region"},
             "kernel_ms_in_flight": dict(zip(("frame", "trace_closest", "shade", "trace_shadow", "rest"), in_flight_stage)),
-            "fast_build": fast,
             # The dominant kernel is the closest-hit trace of the primary rays.  What bounds it is fp32 vector work and the
             # latency of its dependent loads, not HBM: its working set (BVH + triangle records) stays in L2 / Infinity Cache.
             "roofline": {"bound": "valu_fp32", "kernel": "traceKernel<false,false,false> (closest hit, primary rays)",
@@ -567,7 +532,7 @@ def main():
                          "note": f"algorithmic flops = {NODE_FLOPS}/box test + {TRI_FLOPS}/triangle test + {SPHERE_FLOPS}/sphere test + "
                                  f"{MESH_ENTRY_FLOPS}/mesh entry, test counts exact from the counter build of the same kernels in this run; "
                                  "duration = average of 10 launches running alone (one frame in flight), HIP events on the launch stream; "
-                                 "peak = 256 CUs x 4 SIMDs x 32 lanes x 2 (FMA) x 2.4 GHz. The EXACT build may not fuse multiply-adds, so half the "
+                                 "peak = 256 CUs x 4 SIMDs x 32 lanes x 2 (FMA) x 2.4 GHz. The kernels may not fuse multiply-adds (bit-exactness), so half the "
                                  "peak is out of reach by construction; selects, compares, address and stack work are not counted. The "
                                  "counted tests are the reference walk's; the timed launch fetches four grandchildren per node step and tests "
                                  "boxes the reference walk skips, which the algorithmic count leaves out",

@@ -121,7 +121,6 @@ C_ABI = {
     "rt_set_device_bvh": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rt_render_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RtDeviceOpts), C.POINTER(RtCamera), C.c_void_p, C.c_size_t,
                                     C.c_int, C.POINTER(RtFrameAux)]),
-    "rt_set_arithmetic": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_tile_list": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rt_set_tile_cost_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rt_set_accumulation": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]),

@@ -345,10 +345,6 @@ class Context:
     def set_tile_cost_buffer(self, dev_ptr):
         self._check(self.lib.rt_set_tile_cost_buffer(self.ctx, dev_ptr), "rt_set_tile_cost_buffer")
 
-    def set_arithmetic(self, fast):
-        """False = exact (bit-identical to the reference's formulas), True = the fast build of the kernels."""
-        self._check(self.lib.rt_set_arithmetic(self.ctx, 1 if fast else 0), "rt_set_arithmetic")
-
     def stream_wait_frame(self, stream_ptr=None, frames_ago=0):
         self._check(self.lib.rt_stream_wait_frame(self.ctx, stream_ptr, frames_ago), "rt_stream_wait_frame")
 

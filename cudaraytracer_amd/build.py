@@ -26,7 +26,6 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # No SLP vectorisation: packed fp32 instructions issue at half the rate of plain ones on gfx950, so pairs gain nothing
 # and the moves that line their operands up cost issue slots and registers (88 -> 76 VGPRs in the trace kernel).
 DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-std=c++17", "-fPIC"]
-FAST_DEVICE_FLAGS = ["--offload-arch=gfx950", "-O3", "-DRT_FAST=1", "-ffp-contract=on", "-fno-fast-math", "-fno-slp-vectorize", "-std=c++17", "-fPIC"]
 HOST_FLAGS = ["-O2", "-ffp-contract=off", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 
 
@@ -71,9 +70,6 @@ def build_library(force=False, extra_device_flags=(), out=None, tag=""):
         objs.append(obj)
 
     compile_one(os.path.join(CSRC, "kernels", "rt_kernels.hip"), os.path.join(objdir, "rt_kernels.o"), [HIPCC, *DEVICE_FLAGS, *extra_device_flags])
-    # the same source again as the FAST build: fused multiply-adds, approximate division / square root
-    compile_one(os.path.join(CSRC, "kernels", "rt_kernels.hip"), os.path.join(objdir, "rt_kernels_fast.o"),
-                [HIPCC, *FAST_DEVICE_FLAGS, *extra_device_flags])
     # the BVH build kernels take no tuning flags; every variant links the default build's object
     bvh_obj_dir = os.path.join(PKG, "build")
     os.makedirs(bvh_obj_dir, exist_ok=True)

@@ -28,20 +28,6 @@
 // compiled with -ffp-contract=off, IEEE division and square root, denormals on,
 // so hit decisions are bit-identical to a host evaluation of the same formulas.
 // Only powf (gamma, Blinn-Phong) may differ in the last ulp.
-//
-// The file is compiled a second time with -DRT_FAST=1, contraction to fused
-// multiply-adds and approximate division / square root: the FAST build, whose
-// entry points carry the suffix _fast.  It keeps the algorithm, the visiting
-// order and the tie rule, but not the roundings: its results are held to the
-// tolerance of the parity tests (hit keys on >= 99.99 % of the pixels, radiance
-// within 1e-4 relative or one 8-bit step) instead of bit equality.  What decides
-// WHICH primitive a ray hits stays exact there too (primary ray
-// directions, reciprocal directions, the triangle and sphere tests, the change to
-// a mesh's object space), because scenes are full of exact ties - rays through a
-// shared edge of two triangles, coplanar faces of neighbouring boxes - that any
-// change of rounding resolves differently.  Measured on the 16 x 16 cube grid
-// at 640 x 480 with a contracted triangle test: 128 pixels (0.04 %) change their
-// hit key, all of them on cube edges.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -50,15 +36,9 @@
 #include <stdlib.h>
 
 #include "../rt_device_format.h"
+#include "rt_trace_probes.h"
 
-#ifdef RT_FAST
-#define RTK(name) name##_fast
-#else
-#define RTK(name) name
-#endif
-
-// Everything from here to the shading section keeps the reference's roundings in BOTH builds: vector helpers, ray
-// set-up, box / triangle / sphere tests and the trace kernel.
+// No expression in this file may be contracted to a fused multiply-add, whatever the command line says.
 #pragma clang fp contract(off)
 
 namespace {
@@ -95,11 +75,7 @@ __device__ __forceinline__ V3 muls(V3 a, float r) { return mk(a.x * r, a.y * r, 
 __device__ __forceinline__ V3 divs(V3 a, float r) { return mk(a.x / r, a.y / r, a.z / r); }
 __device__ __forceinline__ V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
 // cudaTracer/Vec.cuh:232-238: the sum starts at 0 (keeps the sign-of-zero behaviour)
-#if defined(RT_FAST) && !defined(RT_KEEP_ZERO)
-__device__ __forceinline__ float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-#else
 __device__ __forceinline__ float dot(V3 a, V3 b) { return ((0.0f + a.x * b.x) + a.y * b.y) + a.z * b.z; }
-#endif
 // cudaTracer/Vec.cuh:240-247
 __device__ __forceinline__ V3 cross(V3 a, V3 b) {
     return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
@@ -161,7 +137,7 @@ __device__ __forceinline__ void boxPairSlabs(const float4 n0, const float4 n1, c
 // smaller product is the reference's near-plane distance, formed by the same operations; the reference's comparisons
 // say "every entry <= every exit of ANOTHER axis", and entry <= exit of the SAME axis can only fail when a padded exit
 // distance is negative, where the box fails "exit > 0" in both forms.  A ray lying exactly in a box face (0 * inf) can
-// come out differently, which is why the EXACT build walks rays with an infinite reciprocal direction in a launch of
+// come out differently, which is why rays with an infinite reciprocal direction are walked by a launch of
 // their own with the literal form (see traceKernel).  Both forms inside ONE kernel cost more registers than the
 // shorter form saves instructions (measured: 1 615 against 1 640 Mrays/s).
 __device__ __forceinline__ void boxPairMinMax(const float4 n0, const float4 n1, const float4 n2, const float4 n3, const V3 o, const V3 inv,
@@ -383,11 +359,11 @@ __device__ __forceinline__ bool triangleSolve(const float4 r0, const float4 r1, 
 // direction and chains its comparisons so that a NaN (0 * inf: a ray that lies exactly in a box face) falls a
 // certain way.  Without a NaN the smaller / larger of the two plane distances IS the near / far distance, formed by
 // the same operations (boxPairMinMax), which saves a quarter of a node step's vector instructions.  A NaN needs an
-// infinite reciprocal direction, so in the EXACT build the LIT = false launch walks every ray whose reciprocal
+// infinite reciprocal direction, so the LIT = false launch walks every ray whose reciprocal
 // direction is finite - in world space and in every mesh's object space it enters - and marks the others
 // (HIT_DEFERRED / VIS_DEFERRED, counted in CTL_DEFER_*); a second launch with the literal test (LIT = true, `rescue`)
 // walks the marked rays from the start and ends at once when there is none.  Counter launches, small frames and
-// reflection levels use the literal test for every ray, in one launch (launchTrace).  The FAST build uses the min / max form for all rays and has no second launch.
+// reflection levels use the literal test for every ray, in one launch (launchTrace).
 template <bool ANY, bool COUNT, bool LIT>
 __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FrameParams P, const int level, const int rescue) {
     extern __shared__ uint2 s_dyn[];
@@ -405,11 +381,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     // the world-space ray and the rest of the scene leaf wait here while a mesh is walked
     uint2* const gsave = gstk + (size_t)P.stackEntries * kWave;
 
-#ifdef RT_FAST
-    constexpr bool kDefer = false;
-#else
     constexpr bool kDefer = !LIT;  // rays with an infinite reciprocal direction are left to the rescue launch
-#endif
     // The launches with the min / max box test walk quads (four grandchildren per fetch, rt_device_format.h); counter
     // launches and the launches with the literal box test walk the sibling pairs, test for test as the reference does.
     constexpr bool kQuad = !LIT && !COUNT;
@@ -477,24 +449,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     constexpr bool kSplit = ANY && !COUNT;
     int floorAt = 0;  // first stack entry of the space the ray is walked in now (behind the marker while inside a mesh)
 
-#ifdef RT_STAMPS  // diagnostic build: shader-clock cycles per section of the loop, summed per wavefront (COUNT launches only)
-    unsigned stampAcc[16] = {}, stampCnt[16] = {};
-    unsigned long long stampLast = __builtin_amdgcn_s_memtime();
-#define STAMP(i)                                                          \
-    do {                                                                  \
-        if (COUNT) {                                                      \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   \
-            const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-            stampAcc[i] += (unsigned)(now_ - stampLast);                  \
-            stampCnt[i] += 1u;                                            \
-            stampLast = now_;                                             \
-        }                                                                 \
-    } while (0)
-#else
-#define STAMP(i) \
-    do {         \
-    } while (0)
-#endif
+    RT_PROBE_STATE();  // diagnostic builds only (rt_trace_probes.h)
 
     auto push = [&](unsigned x, unsigned y) {
         if (sp - lo >= ringN) {
@@ -786,53 +741,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     const float4 L0 = p[0], L1 = p[1], L2 = p[2], L3 = p[3];
                     STAMP(2);  // node step: child pair arrived
                     const bool nx = inv.x < 0.0f, ny = inv.y < 0.0f, nz = inv.z < 0.0f;
-#ifdef RT_X_VALU  // sensitivity experiment: RT_X_VALU extra vector instructions per node step, in 8 independent chains
-                    {
-                        float x0 = o.x, x1 = o.y, x2 = o.z, x3 = inv.x, x4 = inv.y, x5 = inv.z, x6 = tMax, x7 = L0.x;
-#pragma unroll
-                        for (int i = 0; i < RT_X_VALU / 8; ++i)
-                            asm volatile("v_add_f32 %0, %0, %8\n v_add_f32 %1, %1, %8\n v_add_f32 %2, %2, %8\n v_add_f32 %3, %3, %8\n"
-                                         "v_add_f32 %4, %4, %8\n v_add_f32 %5, %5, %8\n v_add_f32 %6, %6, %8\n v_add_f32 %7, %7, %8"
-                                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
-                                         : "v"(L1.x));
-                        asm volatile("" ::"v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7));
-                    }
-#endif
-#ifdef RT_X_CMP  // sensitivity experiment: extra compare + select pairs per node step
-                    {
-                        float x0 = o.x, x1 = o.y;
-#pragma unroll
-                        for (int i = 0; i < RT_X_CMP / 2; ++i)
-                            asm volatile("v_cmp_lt_f32 vcc, %0, %2\n v_cndmask_b32 %1, %1, %2, vcc" : "+v"(x0), "+v"(x1) : "v"(L1.x) : "vcc");
-                        asm volatile("" ::"v"(x0), "v"(x1));
-                    }
-#endif
-#ifdef RT_X_LOAD  // sensitivity experiment: RT_X_LOAD extra 16-byte loads per node step, from the line that just arrived
-                    {
-#ifdef RT_X_LOAD_UNIFORM  // every lane reads the same line
-                        const float4* q = blob4 + ((size_t)(lane & 3) << 2);
-#else
-                        const float4* q = p;
-#endif
-                        asm volatile("" : "+v"(q));
-#ifdef RT_X_LOAD_ONE_LANE  // only the first lane of the node step makes the extra loads
-                        if (lane == __ffsll((long long)nodeMask) - 1)
-#endif
-#pragma unroll
-                        for (int i = 0; i < RT_X_LOAD; ++i) {
-                            const float4 x = q[i & 3];
-                            asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w));
-                        }
-                    }
-#endif
-#ifdef RT_X_SALU  // sensitivity experiment: extra scalar instructions per node step
-                    {
-                        unsigned s0 = (unsigned)level;
-#pragma unroll
-                        for (int i = 0; i < RT_X_SALU; ++i) asm volatile("s_add_u32 %0, %0, 1" : "+s"(s0) : : "scc");
-                        asm volatile("" ::"s"(s0));
-                    }
-#endif
+                    RT_PROBE_NODE_STEP();
                     // Lane predicates live in scalar mask registers: every mask below is the ballot of ONE comparison (a
                     // vector compare that writes a scalar register pair) and all the logic on them is scalar arithmetic.
                     const auto B = [](bool c) { return __builtin_amdgcn_ballot_w64(c); };
@@ -1050,13 +959,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
     }
 
     if (COUNT && P.counters) {
-#ifdef RT_STAMPS
-        if (lane == 0)
-            for (int i = 0; i < 16; ++i) {
-                atomicAdd(P.counters + 64 + (ANY ? 32 : 0) + 2 * i, (unsigned long long)stampAcc[i]);
-                atomicAdd(P.counters + 64 + (ANY ? 32 : 0) + 2 * i + 1, (unsigned long long)stampCnt[i]);
-            }
-#endif
+        RT_PROBE_FLUSH();
         unsigned vals[6] = {cNode, cTri, cSphere, cMesh, cRays, cPrimary};
         const int where[6] = {RT_CNT_NODE, RT_CNT_TRI, RT_CNT_SPHERE, RT_CNT_MESH_ENTRY,
                               ANY ? RT_CNT_SHADOW : (level > 0 ? RT_CNT_SECONDARY : -1), ANY ? -1 : RT_CNT_PRIMARY};
@@ -1082,11 +985,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
 }
 
 // ---------------------------------------------------------------------------
-// Shading.  The FAST build contracts the expressions written in this section (texture filtering, interpolation,
-// Fresnel, the light sums); the vector helpers above keep their roundings.
-#ifdef RT_FAST
-#pragma clang fp contract(fast)
-#endif
+// Shading.
 
 // cudaTracer/Texture.cuh:50-69.  WRAP wraps negative indices into range (the
 // reference's C '%' leaves them negative and reads out of bounds).
@@ -1108,23 +1007,14 @@ __device__ __forceinline__ V3 texel(const unsigned char* __restrict__ data, int 
 // cudaTracer/Texture.cuh:33-48: texel-centre offset and the two "1 - ratio"
 // weights go through double; every weight is rounded to float before it scales a colour.
 __device__ __forceinline__ V3 texSample(const unsigned char* __restrict__ data, int w, int h, int mode, float u, float v) {
-#ifdef RT_FAST
-    u = u * (float)w - 0.5f;
-    v = v * (float)h - 0.5f;
-#else
     u = (float)((double)(u * (float)w) - 0.5);
     v = (float)((double)(v * (float)h) - 0.5);
-#endif
     const int x = (int)floorf(u);
     const int y = (int)floorf(v);
     const float ur = u - (float)x;
     const float vr = v - (float)y;
-#ifdef RT_FAST
-    const float uo = 1.0f - ur, vo = 1.0f - vr;
-#else
     const float uo = (float)(1.0 - (double)ur);
     const float vo = (float)(1.0 - (double)vr);
-#endif
     const V3 top = add(muls(texel(data, w, h, mode, x, y), uo), muls(texel(data, w, h, mode, x + 1, y), ur));
     const V3 bot = add(muls(texel(data, w, h, mode, x, y + 1), uo), muls(texel(data, w, h, mode, x + 1, y + 1), ur));
     return add(muls(top, vo), muls(bot, vr));
@@ -1492,13 +1382,8 @@ __global__ void advanceKernel(const FrameParams P, const int level) {
     P.ctl[CTL_DEFER_SHADOW] = 0;
 }
 
-// The box test of each launch kind: counter launches walk every ray with the literal test; the FAST build has only
-// the min / max form.
-#ifdef RT_FAST
-constexpr bool kCountLit = false;
-#else
+// Counter launches walk every ray with the literal box test.
 constexpr bool kCountLit = true;
-#endif
 
 // Resident wavefronts per CU of one trace-kernel variant (register and LDS limits), cached per LDS size.
 template <bool ANY, bool COUNT, bool LIT>
@@ -1534,9 +1419,6 @@ void launchTrace(const FrameParams& p, int level, int cuCount, hipStream_t s) {
         launchOne<ANY, true, kCountLit>(p, level, cuCount, s, 0);
         return;
     }
-#ifdef RT_FAST
-    launchOne<ANY, false, false>(p, level, cuCount, s, 0);
-#else
     // Two launches pay where the rays are: the primary rays of a large frame and their shadow rays.  A kernel
     // boundary costs 15-25 us of an in-order frame, more than the shorter box test saves on a small frame or on the
     // few rays of a reflection level: those are walked by one launch with the literal test.
@@ -1546,26 +1428,22 @@ void launchTrace(const FrameParams& p, int level, int cuCount, hipStream_t s) {
     } else {
         launchOne<ANY, false, true>(p, level, cuCount, s, 0);
     }
-#endif
 }
 
 }  // namespace
 
-int RTK(rtk_trace_waves_per_cu)(int stackLds) {
+int rtk_trace_waves_per_cu(int stackLds) {
     const size_t lds = traceLdsBytes(stackLds);
     // the largest residency of the variants: each launch takes its own, this one sizes the spill buffer
     int w = wavesPerCu<false, false, false>(lds);
     w = std::max(w, wavesPerCu<true, false, false>(lds));
     w = std::max(w, wavesPerCu<false, true, kCountLit>(lds));
     w = std::max(w, wavesPerCu<true, true, kCountLit>(lds));
-#ifndef RT_FAST
     w = std::max(w, wavesPerCu<false, false, true>(lds));
     w = std::max(w, wavesPerCu<true, false, true>(lds));
-#endif
     return w;
 }
 
-#ifndef RT_FAST
 // Workspace of rt_render_noalloc: one array per GPU the library runs on, held until the process ends.  In host
 // code the array's name only stands for the symbol; its address on the current device comes from
 // hipGetSymbolAddress and is what kernels and memory calls are given.
@@ -1580,10 +1458,8 @@ int rtk_scratch(void** devPtr, size_t* bytes) {
     return 0;
 }
 
-#endif
-
 // Enqueues the kernel sequence of one frame on `stream`.
-int RTK(rtk_render_frame)(const FrameParams* frame, int hasSecondary, int count, int cuCount, void* stream, void** stageEvents) {
+int rtk_render_frame(const FrameParams* frame, int hasSecondary, int count, int cuCount, void* stream, void** stageEvents) {
     const FrameParams& p = *frame;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipEvent_t* ev = reinterpret_cast<hipEvent_t*>(stageEvents);

@@ -103,8 +103,7 @@ struct rt_ctx {
         void* dev;
     };
     std::vector<TileOrder> tileOrders;
-    int wavesPerCu = 0, wavesForLds = -1, wavesForMode = -1;
-    int arithmetic = RT_ARITHMETIC_EXACT;  // rt_set_arithmetic
+    int wavesPerCu = 0, wavesForLds = -1;
     // pinned staging for rt_surface_download: two chunks, so that the copy from the device overlaps the copy to the caller
     void* staging[2] = {nullptr, nullptr};
     hipEvent_t stagingDone[2] = {nullptr, nullptr};
@@ -826,13 +825,6 @@ int rt_check_workspace_guards(rt_ctx* ctx) {
     return RT_OK;
 }
 
-int rt_set_arithmetic(rt_ctx* ctx, int mode) {
-    if (!ctx) return RT_ERR_INVALID;
-    if (mode != RT_ARITHMETIC_EXACT && mode != RT_ARITHMETIC_FAST) return fail(ctx, RT_ERR_INVALID, "unknown arithmetic mode %d", mode);
-    ctx->arithmetic = mode;
-    return RT_OK;
-}
-
 int rt_set_path_budget(rt_ctx* ctx, int nodesPerPixel) {
     if (!ctx) return RT_ERR_INVALID;
     if (nodesPerPixel < 1 || nodesPerPixel > 65536) return fail(ctx, RT_ERR_INVALID, "path budget must be in 1..65536");
@@ -1206,13 +1198,10 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
     while (p.stackLds * 2 <= ctx->ldsStack && p.stackLds < p.stackEntries) p.stackLds *= 2;
 
     if (int r = bind(ctx)) return r;
-    const bool fast = ctx->arithmetic == RT_ARITHMETIC_FAST;
-    if (ctx->wavesForLds != p.stackLds || ctx->wavesForMode != ctx->arithmetic) {
-        ctx->wavesPerCu = fast ? rtk_trace_waves_per_cu_fast(p.stackLds) : rtk_trace_waves_per_cu(p.stackLds);
+    if (ctx->wavesForLds != p.stackLds) {
+        ctx->wavesPerCu = rtk_trace_waves_per_cu(p.stackLds);
         ctx->wavesForLds = p.stackLds;
-        ctx->wavesForMode = ctx->arithmetic;
     }
-    const auto renderKernels = fast ? rtk_render_frame_fast : rtk_render_frame;
     p.traceWaves = (ctx->maxWavesPerCu > 0 ? std::min(ctx->wavesPerCu, ctx->maxWavesPerCu) : ctx->wavesPerCu) * ctx->cuCount;
 
     // measured on whole frames, on small reflection levels and on one GPU's share of a multi-GPU frame: 2 and 8 are slower;
@@ -1273,7 +1262,7 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
         p.vis = static_cast<unsigned char*>(w.vis);
         p.stackSpill = static_cast<uint2*>(w.stackSpill);
         p.tileOrder = ctx->tileList;  // else row-major: an order table would have to be uploaded into fresh device memory
-        hipError_t e = (hipError_t)renderKernels(&p, secondary, p.counters ? 1 : 0, ctx->cuCount, ctx->stream, nullptr);
+        hipError_t e = (hipError_t)rtk_render_frame(&p, secondary, p.counters ? 1 : 0, ctx->cuCount, ctx->stream, nullptr);
         if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
         ctx->scratchMayOverflow = ctx->scratchMayOverflow || (secondary && opts->maxDepth > 0);
         if (ctx->accum) ctx->accumSamples += (uint32_t)opts->samples;
@@ -1378,7 +1367,7 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
         RT_HIP(ctx, hipEventRecord(sl.ready, ctx->stream));
         RT_HIP(ctx, hipStreamWaitEvent(exec, sl.ready, 0));
     }
-    hipError_t e = (hipError_t)renderKernels(&p, secondary, p.counters ? 1 : 0, ctx->cuCount, exec, reinterpret_cast<void**>(l.ev));
+    hipError_t e = (hipError_t)rtk_render_frame(&p, secondary, p.counters ? 1 : 0, ctx->cuCount, exec, reinterpret_cast<void**>(l.ev));
     if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
     RT_HIP(ctx, hipEventRecord(sl.done, exec));
     sl.issued = true;

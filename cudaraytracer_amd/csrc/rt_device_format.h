@@ -237,8 +237,6 @@ struct FrameParams {
 // `stageEvents`: optional hipEvent_t[5] recorded at frame start, after the level-0 closest-hit
 // trace, after shading, after the shadow trace, at frame end.  Returns a hipError_t value.
 int rtk_render_frame(const FrameParams* frame, int hasSecondary, int count, int cuCount, void* stream, void** stageEvents);
-// The same from the FAST build of the kernels (shading contracted to fused multiply-adds, min / max box test).
-int rtk_render_frame_fast(const FrameParams* frame, int hasSecondary, int count, int cuCount, void* stream, void** stageEvents);
 // ---- mesh BVH construction on the device (kernels/rt_bvh_build.hip) -------------
 // The tree's shape follows from the primitive count alone (median cuts), so the host writes the
 // node records' references and this work table; the device orders the primitives and fills in
@@ -276,6 +274,5 @@ int rtk_scratch(void** devPtr, size_t* bytes);
 
 // Resident wavefronts per CU of the trace kernels for a given LDS stack size.
 int rtk_trace_waves_per_cu(int stackLds);
-int rtk_trace_waves_per_cu_fast(int stackLds);
 
 #endif

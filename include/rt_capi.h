@@ -330,21 +330,6 @@ int rt_timing_read_stages(rt_ctx* ctx, double* totalMs, double* stageMs, int* la
  * them) and the next rt_sync returns RT_ERR_LIMIT, however many frames were rendered in between. */
 int rt_set_path_budget(rt_ctx* ctx, int nodesPerPixel);
 
-/* Arithmetic of the render kernels.
- *   RT_ARITHMETIC_EXACT (default): every fp32 operation of the trace / shade path in the reference's operation
- *     order, no fused multiply-adds, IEEE division and square root: hit decisions and radiance are bit-identical to
- *     a host evaluation of the reference's formulas (cudaTracer/tracer.cu, Mesh.cuh, Sphere.cuh, BoundingBox.cuh).
- *   RT_ARITHMETIC_FAST: the same kernels with the shading expressions contracted to fused multiply-adds, fp32
- *     texture weights, and the min / max form of the box test for EVERY ray (EXACT gives rays that run along an axis
- *     plane a launch of their own with the reference's literal comparison chain, whose outcome for a ray lying in a
- *     box face - a NaN plane distance - the min / max form does not reproduce).  Same algorithm, visiting order
- *     and tie rule; results agree with EXACT within the parity tolerance (hit keys on >= 99.99 % of the pixels,
- *     radiance within 1e-4 relative or one 8-bit step), not bit for bit.
- * The reference has one build (nvcc's default contracts to FMA, cudaTracer/cudaTracer.vcxproj). */
-#define RT_ARITHMETIC_EXACT 0
-#define RT_ARITHMETIC_FAST 1
-int rt_set_arithmetic(rt_ctx* ctx, int mode);
-
 /* Diagnostic: every workspace array allocated from now on gets `bytes` (a multiple of 256, 0 = none) of guard
  * band behind it, filled with a pattern; rt_check_workspace_guards waits for the frames in flight and returns
  * RT_ERR_DEVICE naming the array if a kernel wrote past an array's end.  The reference has no counterpart. */
@@ -427,7 +412,7 @@ int rt_set_tile_cost_buffer(rt_ctx* ctx, uint32_t* devCost);
  * depend on it. */
 int rt_set_lds_stack(rt_ctx* ctx, int entries);
 
-/* Box test of the EXACT build.  The reference's slab test (cudaTracer/BoundingBox.cuh:115-139) equals its min / max
+/* Box test.  The reference's slab test (cudaTracer/BoundingBox.cuh:115-139) equals its min / max
  * form - fewer instructions - bit for bit unless a plane distance is a NaN, which takes an infinite reciprocal
  * direction.  The trace of a frame's primary rays, and of their shadow rays, therefore runs as two launches when the
  * call renders at least `minRays` primary rays (default 100000; INT_MAX = never): the first walks the rays with a

@@ -43,6 +43,7 @@ def gpu_ctx():
 @pytest.fixture(scope="session")
 def synthetic_assets(tmp_path_factory):
     """An asset directory shaped like the reference's (OBJ barrel + 1024x1024 PNG maps + plane textures), written once."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
     import synth_assets
 
     return synth_assets.write_assets(tmp_path_factory.mktemp("assets"))

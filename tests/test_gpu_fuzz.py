@@ -115,30 +115,3 @@ def test_random_scene_matches_oracle(gpu_ctx, oracle, rtlib, seed):
     assert np.array_equal(np.isnan(rgba), np.isnan(ref_rgba))
     r = compare(rgba, keys, ref_rgba, ref_keys)
     assert r["max_rel"] <= 1e-6 and r["radiance_ok_fraction"] == 1.0, r
-
-
-def test_random_scenes_with_the_fast_build(gpu_ctx, oracle, rtlib):
-    """The FAST build (fused multiply-adds, min / max box test for every ray) against the EXACT oracle over all the
-    random scenes together: the task's tolerance, >= 99.99 % of the hit keys and radiance within 1e-4 or one 8-bit step
-    wherever the keys agree."""
-    pixels = differing = 0
-    gpu_ctx.set_arithmetic(True)
-    gpu_ctx.set_path_budget(16)
-    try:
-        for seed in range(96):
-            scene = random_scene(rtlib, seed)
-            ref_rgba, ref_keys = scene.render_oracle(oracle)
-            rgba, keys = scene.render_gpu(gpu_ctx)
-            same = (keys == ref_keys).all(-1)
-            pixels += same.size
-            differing += int((~same).sum())
-            # Where the primary hit is the same, so is the radiance - unless a reflected or refracted ray met a different
-            # surface; those pixels are counted as differing too.
-            r = compare(rgba[same], None, ref_rgba[same], None) if same.any() else None
-            if r is not None and r["radiance_ok_fraction"] < 1.0:
-                differing += int(round((1.0 - r["radiance_ok_fraction"]) * int(same.sum())))
-    finally:
-        gpu_ctx.set_arithmetic(False)
-        gpu_ctx.set_path_budget(3)
-    print(f"FAST build: {differing} of {pixels} pixels differ")
-    assert differing <= 1e-4 * pixels + 1, (differing, pixels)

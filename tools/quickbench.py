@@ -27,7 +27,6 @@ ap.add_argument("--frames-in-flight", type=int, default=0)
 ap.add_argument("--waves", type=int, default=0)
 ap.add_argument("--split", type=int, default=-1, help="rt_set_box_test_split: level-0 traces of at least this many rays run as two launches")
 ap.add_argument("--cost-order", action="store_true", help="tiles in order of falling cost, measured by a counter frame (rt_set_tile_list)")
-ap.add_argument("--fast", action="store_true", help="the FAST build of the kernels (rt_set_arithmetic)")
 ap.add_argument("--tile-order", type=int, default=-1)
 ap.add_argument("--device-bvh", action="store_true")
 ap.add_argument("--sah", action="store_true", help="mesh BVHs cut by the binned surface-area heuristic (host build)")
@@ -40,7 +39,7 @@ assets = a.assets
 if assets == "synthetic":
     import tempfile
 
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import synth_assets
 
     assets = synth_assets.write_assets(tempfile.mkdtemp(prefix="rt_assets_"))
@@ -53,8 +52,6 @@ with rt.Context(0) as ctx:
         ctx.set_trace_waves(a.waves)
     if a.split >= 0:
         ctx.set_box_test_split(a.split)
-    if a.fast:
-        ctx.set_arithmetic(True)
     if a.tile_order >= 0:
         ctx.set_tile_order(a.tile_order)
     if a.frames_in_flight:
