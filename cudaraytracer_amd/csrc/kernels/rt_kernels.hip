@@ -32,6 +32,8 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -212,6 +214,12 @@ __device__ __forceinline__ int slotSample(const FrameParams& P, int slot) {
     return P.opts.samples == 1 ? 0 : (slot >> 6) % P.opts.samples;
 }
 
+// Samples a pixel holds from earlier calls when accumulating over frames: its own count in the running-sum surface, so
+// that a frame rendered shard by shard (or tile list by tile list) advances pixel by pixel.  0 without accumulation.
+__device__ __forceinline__ uint32_t pixelSampleBase(const FrameParams& P, int x, int y) {
+    return P.accum ? (uint32_t) reinterpret_cast<const float*>(P.accum + (size_t)y * P.accumPitch + (size_t)x * 16)[3] : 0u;
+}
+
 // Primary ray direction, cudaTracer/Main.cu:57-75.  With one sample both jitters are exactly 0.0f.
 __device__ __forceinline__ V3 primaryDir(const FrameParams& P, int x, int y, int sample) {
     const float widthScale = 1.0f / (float)P.opts.width;
@@ -220,10 +228,11 @@ __device__ __forceinline__ V3 primaryDir(const FrameParams& P, int x, int y, int
     const float ndcY = (1.0f - 2.0f * ((float)y + 0.5f) * heightScale) * P.opts.scale;
     float xJitter = 0.0f, yJitter = 0.0f;
     if (P.opts.samples > 1 || P.accum) {
-        // accumulating over frames, this call's samples continue the numbering of the earlier calls
+        // accumulating over frames, this call's samples continue the numbering of the pixel's earlier ones
         const uint32_t pixel = (uint32_t)y * (uint32_t)P.opts.width + (uint32_t)x;
-        xJitter = rt_sample_jitter(P.sampleSeed, pixel, P.sampleBase + (uint32_t)sample, 0u);
-        yJitter = rt_sample_jitter(P.sampleSeed, pixel, P.sampleBase + (uint32_t)sample, 1u);
+        const uint32_t k = pixelSampleBase(P, x, y) + (uint32_t)sample;
+        xJitter = rt_sample_jitter(P.sampleSeed, pixel, k, 0u);
+        yJitter = rt_sample_jitter(P.sampleSeed, pixel, k, 1u);
     }
     V3 dir = normalized(mk(ndcX + xJitter * widthScale, ndcY + yJitter * heightScale, 1.0f));
     const float* C = P.camera;
@@ -1124,10 +1133,10 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams P, const in
             } else if (shapeSlot < 0) {
                 P.color[node] = make_float4(bg.x, bg.y, bg.z, 0.0f);
                 P.kind[node] = NODE_DONE;
-                if (level == 0 && P.hitKeys && P.sampleBase + (uint32_t)slotSample(P, node) == 0u) {
+                if (level == 0 && P.hitKeys && slotSample(P, node) == 0) {
                     int x, y;
                     slotPixel(P, node, x, y);
-                    *reinterpret_cast<int4*>(P.hitKeys + ((size_t)y * P.opts.width + x) * 4) = make_int4(-1, -1, -1, -1);
+                    if (pixelSampleBase(P, x, y) == 0u) *reinterpret_cast<int4*>(P.hitKeys + ((size_t)y * P.opts.width + x) * 4) = make_int4(-1, -1, -1, -1);
                 }
             } else {
                 V3 ro;
@@ -1149,10 +1158,10 @@ __global__ void __launch_bounds__(256) shadeKernel(const FrameParams P, const in
                     key.w = rec->idx[2];
                     if (COUNT) cMesh++;
                 }
-                if (level == 0 && P.hitKeys && P.sampleBase + (uint32_t)slotSample(P, node) == 0u) {
+                if (level == 0 && P.hitKeys && slotSample(P, node) == 0) {
                     int x, y;
                     slotPixel(P, node, x, y);
-                    *reinterpret_cast<int4*>(P.hitKeys + ((size_t)y * P.opts.width + x) * 4) = key;
+                    if (pixelSampleBase(P, x, y) == 0u) *reinterpret_cast<int4*>(P.hitKeys + ((size_t)y * P.opts.width + x) * 4) = key;
                 }
                 materialType = shape.materialType;
                 ior = shape.ior;
@@ -1332,13 +1341,19 @@ __global__ void __launch_bounds__(256) finalizeKernel(const FrameParams P) {
         int x, y;
         if (!slotPixel(P, (int)first, x, y)) continue;
         // cudaTracer/Main.cu:66-82: the samples are added up in order, starting from zero, then divided
-        // Accumulating over frames (rt_set_accumulation), the sum continues where the previous call left it, sample by
-        // sample in the same order, so that N calls of one sample add up exactly like one call of N samples.
+        // Accumulating over frames (rt_set_accumulation), the sum continues where the pixel's previous call left it, sample
+        // by sample in the same order, so that N calls of one sample add up exactly like one call of N samples.  (A new
+        // accumulation starts from a cleared surface: sum 0, count 0.)
         V3 col = mk(0.0f, 0.0f, 0.0f);
         float4* const sum = P.accum ? reinterpret_cast<float4*>(P.accum + (size_t)y * P.accumPitch + (size_t)x * 16) : nullptr;
-        if (sum && P.sampleBase != 0u) col = mk(*sum);
+        uint32_t base = 0u;
+        if (sum) {
+            const float4 sofar = *sum;
+            col = mk(sofar);
+            base = (uint32_t)sofar.w;
+        }
         for (int i = 0; i < S; ++i) col = add(col, mk(P.color[first + ((unsigned)i << 6)]));
-        const float samples = (float)(P.sampleBase + (uint32_t)S);
+        const float samples = (float)(base + (uint32_t)S);
         if (sum) *sum = make_float4(col.x, col.y, col.z, samples);
         col = mk(col.x / samples, col.y / samples, col.z / samples);
         float4 out;
@@ -1385,20 +1400,23 @@ __global__ void advanceKernel(const FrameParams P, const int level) {
 // Counter launches walk every ray with the literal box test.
 constexpr bool kCountLit = true;
 
-// Resident wavefronts per CU of one trace-kernel variant (register and LDS limits), cached per LDS size.
+// Resident wavefronts per CU of one trace-kernel variant (register and LDS limits).  Asked once per LDS size and kept in a
+// small table; contexts of several host threads (one per GPU) share it under a lock.  The figure is a property of the
+// code object and the LDS size, the same on every gfx950 device.
 template <bool ANY, bool COUNT, bool LIT>
 int wavesPerCu(size_t lds) {
-    static size_t cachedLds = ~(size_t)0;
-    static int cached = 0;
-    if (lds != cachedLds) {
-        int perCu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, traceKernel<ANY, COUNT, LIT>, kWave, lds) != hipSuccess || perCu < 1) perCu = 8;
-        cached = perCu > 32 ? 32 : perCu;
-        cachedLds = lds;
-        if (getenv("RT_TRACE_DEBUG"))
-            fprintf(stderr, "traceKernel<%d,%d,%d>: %d resident wavefronts per CU with %zu B LDS\n", (int)ANY, (int)COUNT, (int)LIT, cached, lds);
-    }
-    return cached;
+    static std::mutex lock;
+    static std::map<size_t, int> known;
+    std::lock_guard<std::mutex> guard(lock);
+    const auto it = known.find(lds);
+    if (it != known.end()) return it->second;
+    int perCu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, traceKernel<ANY, COUNT, LIT>, kWave, lds) != hipSuccess || perCu < 1) perCu = 8;
+    perCu = perCu > 32 ? 32 : perCu;
+    known[lds] = perCu;
+    if (getenv("RT_TRACE_DEBUG"))
+        fprintf(stderr, "traceKernel<%d,%d,%d>: %d resident wavefronts per CU with %zu B LDS\n", (int)ANY, (int)COUNT, (int)LIT, perCu, lds);
+    return perCu;
 }
 
 // The grid is persistent: exactly as many wavefronts as stay resident for this variant, capped by

@@ -94,7 +94,9 @@ struct rt_ctx {
     // rt_set_accumulation: running sum surface and the samples it holds
     unsigned char* accum = nullptr;
     size_t accumPitch = 0;
-    uint32_t accumSamples = 0;
+    uint32_t accumSamples = 0;  // upper bound of any pixel's count (every call adds its samples), for the 2^24 limit
+    bool accumFresh = false;    // a new accumulation: the next call clears the surface before it renders
+    uint32_t overflowSeen = 0;  // overflow word of a workspace that was regrown before rt_sync could read it
     BuildParams bvhBuild;  // for meshes that arrive without BVH nodes
     int tileOrderMode = RT_TILE_ORDER_CENTER_OUT;
     // tile orders already on the device, by (tile grid, shard, frame size); a table is never changed once made
@@ -553,6 +555,12 @@ int ensureWorkspace(rt_ctx* ctx, Workspace& w, hipStream_t stream, int nodeCap, 
     }
     if (w.ctl && nodeCap <= w.nodeCap && lights <= w.lightCap && secCap <= w.secCap && guard == w.guardBytes) return RT_OK;
     RT_HIP(ctx, hipStreamSynchronize(stream));  // the slot's previous frame may still use the old arrays
+    if (w.ctl) {
+        // the sticky overflow word leaves with the old control block: keep it for rt_sync
+        uint32_t word = 0;
+        RT_HIP(ctx, hipMemcpy(&word, static_cast<uint32_t*>(w.ctl) + CTL_OVERFLOW, sizeof word, hipMemcpyDeviceToHost));
+        ctx->overflowSeen |= word;
+    }
     const int nc = std::max(nodeCap, w.nodeCap), lc = std::max(std::max(lights, 1), w.lightCap), sc = std::max(secCap, w.secCap);
     {
         void* keepSpill = w.stackSpill;
@@ -672,7 +680,8 @@ int rt_sync(rt_ctx* ctx) {
     if (!ctx) return RT_ERR_INVALID;
     if (int r = bind(ctx)) return r;
     if (int r = syncFrames(ctx)) return r;
-    uint32_t overflow = 0;
+    uint32_t overflow = ctx->overflowSeen;
+    ctx->overflowSeen = 0;
     for (FrameSlot& sl : ctx->slots) {
         // only frames that spawn child rays can run out of path nodes
         if (!sl.ws.ctl || !sl.mayOverflow) continue;
@@ -737,26 +746,30 @@ int rt_set_tile_list(rt_ctx* ctx, const int32_t* tiles, int count) {
     if (!ctx) return RT_ERR_INVALID;
     if (count < 0 || (count > 0 && !tiles)) return fail(ctx, RT_ERR_INVALID, "bad tile list");
     if (int r = bind(ctx)) return r;
-    if (int r = syncFrames(ctx)) return r;  // frames in flight may still read the old list
-    if (ctx->tileList) hipFree(ctx->tileList);
-    ctx->tileList = nullptr;
-    ctx->tileListCnt = 0;
-    ctx->tileListMax = -1;
-    if (count == 0) return RT_OK;
-    std::vector<int32_t> sorted(tiles, tiles + count);
-    std::sort(sorted.begin(), sorted.end());
-    if (sorted.front() < 0) return fail(ctx, RT_ERR_INVALID, "negative tile index in the tile list");
-    if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return fail(ctx, RT_ERR_INVALID, "tile %d appears twice in the tile list", *std::adjacent_find(sorted.begin(), sorted.end()));
+    // validate and upload the new list first: a rejected call leaves the current list in place
     void* dev = nullptr;
-    RT_HIP(ctx, hipMalloc(&dev, (size_t)count * sizeof(int32_t)));
-    hipError_t e = uploadNow(dev, tiles, (size_t)count * sizeof(int32_t), ctx->stream);
-    if (e != hipSuccess) {
-        hipFree(dev);
-        return fail(ctx, RT_ERR_DEVICE, "tile list upload: %s", hipGetErrorString(e));
+    int32_t largest = -1;
+    if (count > 0) {
+        std::vector<int32_t> sorted(tiles, tiles + count);
+        std::sort(sorted.begin(), sorted.end());
+        if (sorted.front() < 0) return fail(ctx, RT_ERR_INVALID, "negative tile index in the tile list");
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) return fail(ctx, RT_ERR_INVALID, "tile %d appears twice in the tile list", *std::adjacent_find(sorted.begin(), sorted.end()));
+        largest = sorted.back();
+        RT_HIP(ctx, hipMalloc(&dev, (size_t)count * sizeof(int32_t)));
+        hipError_t e = uploadNow(dev, tiles, (size_t)count * sizeof(int32_t), ctx->stream);
+        if (e != hipSuccess) {
+            hipFree(dev);
+            return fail(ctx, RT_ERR_DEVICE, "tile list upload: %s", hipGetErrorString(e));
+        }
     }
+    if (int r = syncFrames(ctx)) {  // frames in flight may still read the old list
+        if (dev) hipFree(dev);
+        return r;
+    }
+    if (ctx->tileList) hipFree(ctx->tileList);
     ctx->tileList = static_cast<int32_t*>(dev);
     ctx->tileListCnt = count;
-    ctx->tileListMax = sorted.back();
+    ctx->tileListMax = largest;
     return RT_OK;
 }
 
@@ -773,6 +786,7 @@ int rt_set_accumulation(rt_ctx* ctx, void* devSum, size_t sumPitch, uint32_t sam
     ctx->accum = static_cast<unsigned char*>(devSum);
     ctx->accumPitch = devSum ? sumPitch : 0;
     ctx->accumSamples = devSum ? samplesSoFar : 0;
+    ctx->accumFresh = devSum && samplesSoFar == 0;
     return RT_OK;
 }
 
@@ -1135,6 +1149,16 @@ void rt_device_free(rt_ctx* ctx, void* devPtr) {
 
 namespace {
 
+// A new accumulation (rt_set_accumulation with samplesSoFar = 0) starts from a cleared running-sum surface: every
+// pixel's sum and sample count are zero.  Enqueued once, in front of the first frame that accumulates (a memset
+// allocates nothing).
+int startAccumulation(rt_ctx* ctx, const RtDeviceOpts* opts, hipStream_t stream) {
+    if (!ctx->accum || !ctx->accumFresh) return RT_OK;
+    RT_HIP(ctx, hipMemset2DAsync(ctx->accum, ctx->accumPitch, 0, (size_t)opts->width * 16, (size_t)opts->height, stream));
+    ctx->accumFresh = false;
+    return RT_OK;
+}
+
 // Body of rt_render and rt_render_noalloc.  `noAlloc`: the frame's workspace is carved from the device's static
 // scratch array, the frame runs on the context's stream, in order, with row-major tile order and without timing
 // events, and nothing on the way allocates or frees.
@@ -1221,7 +1245,6 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
             return fail(ctx, RT_ERR_LIMIT, "accumulation holds at most 2^24 samples per pixel (the count is kept in fp32)");
         p.accum = ctx->accum;
         p.accumPitch = ctx->accumPitch;
-        p.sampleBase = ctx->accumSamples;
     }
     p.nodeCap = p.slots * budget;
 
@@ -1262,6 +1285,7 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
         p.vis = static_cast<unsigned char*>(w.vis);
         p.stackSpill = static_cast<uint2*>(w.stackSpill);
         p.tileOrder = ctx->tileList;  // else row-major: an order table would have to be uploaded into fresh device memory
+        if (int r = startAccumulation(ctx, opts, ctx->stream)) return r;
         hipError_t e = (hipError_t)rtk_render_frame(&p, secondary, p.counters ? 1 : 0, ctx->cuCount, ctx->stream, nullptr);
         if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
         ctx->scratchMayOverflow = ctx->scratchMayOverflow || (secondary && opts->maxDepth > 0);
@@ -1367,6 +1391,7 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
         RT_HIP(ctx, hipEventRecord(sl.ready, ctx->stream));
         RT_HIP(ctx, hipStreamWaitEvent(exec, sl.ready, 0));
     }
+    if (int r = startAccumulation(ctx, opts, exec)) return r;
     hipError_t e = (hipError_t)rtk_render_frame(&p, secondary, p.counters ? 1 : 0, ctx->cuCount, exec, reinterpret_cast<void**>(l.ev));
     if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "kernel launch: %s", hipGetErrorString(e));
     RT_HIP(ctx, hipEventRecord(sl.done, exec));

@@ -201,8 +201,7 @@ struct FrameParams {
     const int32_t* tileOrder;                // optional [tileCnt]: frame tile of local tile k (overrides the arithmetic rule)
     int32_t slots;                           // tileCnt * samples * 64 level-0 nodes
     uint32_t sampleSeed;
-    uint32_t sampleBase;                     // samples of earlier calls when accumulating over frames (else 0)
-    unsigned char* accum;                    // optional running sum surface: float4 {sum r, g, b, samples} per pixel
+    unsigned char* accum;                    // optional running sum surface: float4 {sum r, g, b, samples so far} per pixel
     uint64_t accumPitch;
     int32_t nodeCap;                         // capacity of the per-node arrays
     int32_t stackEntries;                    // per-lane traversal stack entries needed (8 bytes each)

@@ -327,7 +327,10 @@ int rt_timing_read_stages(rt_ctx* ctx, double* totalMs, double* stageMs, int* la
 /* Mirror / glass materials spawn child rays (cudaTracer/tracer.cu:117-142); the
  * per-frame node arrays hold `nodesPerPixel` x pixels path nodes (default 3).
  * A frame that needs more drops the child rays that do not fit (their parents take the background colour for
- * them) and the next rt_sync returns RT_ERR_LIMIT, however many frames were rendered in between. */
+ * them) and the next rt_sync returns RT_ERR_LIMIT, however many frames were rendered in between (and whether or not
+ * a larger frame made the library regrow its workspace meanwhile).  rt_render_noalloc keeps the flag in the GPU's one
+ * scratch array, which all contexts on that GPU share: there the report goes to whichever of them calls rt_sync
+ * first after the frame. */
 int rt_set_path_budget(rt_ctx* ctx, int nodesPerPixel);
 
 /* Diagnostic: every workspace array allocated from now on gets `bytes` (a multiple of 256, 0 = none) of guard
@@ -378,9 +381,14 @@ int rt_set_sample_seed(rt_ctx* ctx, uint32_t seed);
  *   - adds them to the sums one after the other, in order, and
  *   - writes to the frame surface the average over ALL samples so far, gamma-corrected as Main.cu:80-98 does.
  * N calls of one sample therefore give, bit for bit, the frame of one call with N samples (and any other split of
- * N).  `samplesSoFar` = 0 starts a new accumulation (the surface's old contents are ignored); the library counts on
- * from there.  devSum = NULL ends it.  Frames must run in order (rt_set_frames_in_flight(1)); with tile shards every
- * call accumulates its own tiles.  At most 2^24 samples per pixel. */
+ * N).  Every PIXEL counts its own samples (the fourth float of its sum), so a frame may be rendered in several calls
+ * - tile shards (RtFrameAux.tileStride) or tile lists - in any order: each call continues the pixels it renders.
+ * `samplesSoFar` = 0 starts a new accumulation: the next render call clears the surface (opts->width x opts->height
+ * pixels) before it renders.  Any other value continues the surface as it is - the counts in it are the truth - and is
+ * only the caller's statement of the largest count in it, for the limit below.  devSum = NULL ends it.  Frames must
+ * run in order (rt_set_frames_in_flight(1)).  At most 2^24 samples per pixel (the count is kept in fp32); the library
+ * checks that against samplesSoFar + the samples of all calls since, which over-counts when a frame takes several
+ * calls. */
 int rt_set_accumulation(rt_ctx* ctx, void* devSum, size_t sumPitch, uint32_t samplesSoFar);
 
 /* Order in which a call's 8x8 tiles enter the trace kernels' work queue.  Which tiles

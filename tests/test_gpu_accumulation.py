@@ -87,3 +87,42 @@ def test_accumulation_needs_frames_in_order(gpu_ctx):
         gpu_ctx.free(surf)
         gpu_ctx.free(acc)
         gpu_ctx.free_scene(dscene)
+
+
+@pytest.mark.parametrize("noalloc", [False, True])
+def test_accumulation_of_frames_rendered_shard_by_shard(gpu_ctx, noalloc):
+    """N one-sample frames, each rendered as four tile shards on ONE context, equal one N-sample frame bit for bit:
+    every pixel continues from its own sample count, whichever call renders it and in whatever order the shards come."""
+    w, h, total, shards = 101, 67, 6, 4
+    scene = rt.HostScene("mixed", w, h, 0, 3, 2)
+    o = scene.opts.contents
+    gpu_ctx.set_sample_seed(4242)
+    dscene = gpu_ctx.upload(scene)
+    surf, pitch = gpu_ctx.surface(w, h)
+    acc, apitch = gpu_ctx.surface(w, h)  # 0x01 bytes: a new accumulation must not read them
+    keys = gpu_ctx.alloc(w * h * 16)
+    render = gpu_ctx.render_noalloc if noalloc else gpu_ctx.render
+    try:
+        o.samples = total
+        gpu_ctx.render(dscene, scene.opts, scene.camera, surf, pitch, keys)
+        gpu_ctx.sync()
+        whole = gpu_ctx.download_surface(surf, pitch, w, h)
+        whole_keys = gpu_ctx.download(keys, (h, w, 4), np.int32)
+        o.samples = 1
+        gpu_ctx.zero(keys, w * h * 16)
+        gpu_ctx.set_accumulation(acc, apitch, 0)
+        for frame in range(total):
+            order = list(range(shards)) if frame % 2 == 0 else list(reversed(range(shards)))
+            for first in order:
+                render(dscene, scene.opts, scene.camera, surf, pitch, keys, None, first, shards)
+        gpu_ctx.sync()
+        assert _same(gpu_ctx.download_surface(surf, pitch, w, h), whole)
+        assert np.array_equal(gpu_ctx.download(keys, (h, w, 4), np.int32), whole_keys)
+        assert (gpu_ctx.download_surface(acc, apitch, w, h)[..., 3] == total).all()
+    finally:
+        gpu_ctx.set_accumulation(None)
+        gpu_ctx.set_sample_seed(1234)
+        o.samples = 1
+        for p in (surf, acc, keys):
+            gpu_ctx.free(p)
+        gpu_ctx.free_scene(dscene)

@@ -321,8 +321,20 @@ def test_cost_balanced_tile_lists_compose_the_frame(gpu_ctx, world):
         gpu_ctx.set_tile_list([0, tx * ty])
         with pytest.raises(rt.RtError, match="tiles"):
             gpu_ctx.render(dscene, scene.opts, scene.camera, surf, pitch)
+        gpu_ctx.set_tile_list([2, 7])
         with pytest.raises(rt.RtError, match="twice"):
             gpu_ctx.set_tile_list([3, 5, 3])
+        with pytest.raises(rt.RtError, match="negative"):
+            gpu_ctx.set_tile_list([4, -1])
+        # a rejected list leaves the current one in place: the next call renders tiles 2 and 7 and nothing else
+        gpu_ctx.zero(surf, pitch * h)
+        gpu_ctx.render(dscene, scene.opts, scene.camera, surf, pitch)
+        gpu_ctx.sync()
+        got = gpu_ctx.download_surface(surf, pitch, w, h)
+        drawn = np.zeros((h, w), dtype=bool)
+        for t in (2, 7):
+            drawn[(t // tx) * 8:(t // tx) * 8 + 8, (t % tx) * 8:(t % tx) * 8 + 8] = True
+        assert np.array_equal(got[drawn], full[0][drawn], equal_nan=True) and (got[~drawn] == 0).all()
     finally:
         gpu_ctx.set_tile_list(None)
         gpu_ctx.set_tile_cost_buffer(None)
@@ -538,6 +550,26 @@ def test_full_size_soup_frame_and_properties(gpu_ctx, oracle):
         assert 0.3 < hit.mean() < 0.9
         again = gpu_ctx.render_frame(scene, dscene, want_keys=True)
         assert np.array_equal(again[1], keys) and np.array_equal(again[0], rgba, equal_nan=True)
+    finally:
+        gpu_ctx.free_scene(dscene)
+
+
+def test_headline_scene_on_its_own_tree_at_full_size(gpu_ctx, oracle):
+    """The bench's headline exactly: 1080p over the 1M-triangle soup on the tight-bounds tree cut by the binned
+    surface-area heuristic (unbalanced, deeper than the median-cut tree above).  Whole frame against the oracle: every
+    hit key, the radiance, and integer-equal test counters."""
+    w, h = 1920, 1080
+    scene = rt.HostScene("soup", w, h, 1000000, 1, 0, tight_bvh=True, sah_bvh=True)
+    dscene = gpu_ctx.upload(scene)
+    try:
+        rgba, keys, cnt = gpu_ctx.render_frame(scene, dscene, want_keys=True, want_counters=True)
+        ref_rgba, ref_keys, ref_cnt = oracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=16, shadow_any_hit=True)
+        r = assert_parity(rgba, keys, ref_rgba, ref_keys)
+        assert r["key_mismatches"] == 0 and cnt == ref_cnt, (r, cnt, ref_cnt)
+        assert cnt["primary"] == w * h and cnt["shadow"] == int((keys[..., 0] >= 0).sum())
+        # the plain build (quad walk, two launches per trace) renders the counter build's frame
+        plain = gpu_ctx.render_frame(scene, dscene, want_keys=True)
+        assert np.array_equal(plain[1], keys) and np.array_equal(plain[0], rgba, equal_nan=True)
     finally:
         gpu_ctx.free_scene(dscene)
 

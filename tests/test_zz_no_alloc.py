@@ -46,6 +46,37 @@ def test_noalloc_matches_rt_render_on_consecutive_calls():
         ctx.close()
 
 
+def test_noalloc_calls_leave_free_device_memory_unchanged():
+    """The contract "no hipMalloc / hipFree": after a warm-up call (module load, first-use set-up), free device memory as
+    hipMemGetInfo reports it stays the same over a series of rt_render_noalloc calls of different sizes, with and
+    without counters, with a tile list set beforehand."""
+    import torch
+
+    ctx = rt.Context(0)
+    try:
+        scenes = [rt.HostScene("mixed", 160, 120, 0, 3, 3), rt.HostScene("cubes", 96, 64, 4, 2, 0)]
+        dscenes = [ctx.upload(s) for s in scenes]
+        bufs = [(ctx.surface(s.width, s.height), ctx.alloc(s.width * s.height * 16), ctx.alloc(rt.RT_COUNTER_CNT * 8)) for s in scenes]
+        ctx.set_tile_list(list(range(0, 96, 3)))
+        for s, d, ((surf, pitch), keys, cnt) in zip(scenes, dscenes, bufs):  # warm-up
+            ctx.render_noalloc(d, s.opts, s.camera, surf, pitch, keys, cnt)
+        ctx.sync()
+        torch.cuda.synchronize()
+        free_before = torch.cuda.mem_get_info(0)[0]
+        for rep in range(3):
+            for s, d, ((surf, pitch), keys, cnt) in zip(scenes, dscenes, bufs):
+                ctx.render_noalloc(d, s.opts, s.camera, surf, pitch, keys if rep % 2 else None, cnt if rep == 2 else None)
+        ctx.sync()
+        assert torch.cuda.mem_get_info(0)[0] == free_before
+        # the allocating entry point does move it on a fresh context (first workspace): the probe can see an allocation
+        ctx.set_tile_list(None)
+        ctx.render(dscenes[0], scenes[0].opts, scenes[0].camera, bufs[0][0][0], bufs[0][0][1])
+        ctx.sync()
+        assert torch.cuda.mem_get_info(0)[0] < free_before
+    finally:
+        ctx.close()
+
+
 def test_noalloc_tile_shards_and_limit():
     ctx = rt.Context(0)
     try:
