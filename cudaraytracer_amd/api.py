@@ -319,6 +319,10 @@ class Context:
         """Parameters of the on-device BVH build used for meshes that come without nodes."""
         self._check(self.lib.rt_set_device_bvh(self.ctx, threshold, 1 if tight_bounds else 0), "rt_set_device_bvh")
 
+    def set_upload_refit(self, on=True):
+        """Recompute the boxes of the trees a scene arrives with at upload (same topology, true bounds)."""
+        self._check(self.lib.rt_set_upload_refit(self.ctx, 1 if on else 0), "rt_set_upload_refit")
+
     def set_sample_seed(self, seed):
         self._check(self.lib.rt_set_sample_seed(self.ctx, seed), "rt_set_sample_seed")
 

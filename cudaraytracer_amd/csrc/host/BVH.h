@@ -25,6 +25,9 @@
 // triangle tests per ray).  TIGHT_BOUNDS starts every union from a true empty
 // box (+FLT_MAX / -FLT_MAX) and is otherwise the same algorithm; hits are the
 // same except for equal-distance ties, which depend on visiting order.
+// What the C++ driver (RayTracer.h) gets by default is a third thing: trees BUILT with REFERENCE_BOUNDS - the
+// reference's shape, leaf order and ties, node for node - whose boxes the library recomputes on the device when the
+// scene is uploaded (RayTracer::refitAtUpload, rt_set_upload_refit), so that rays walk true bounds.
 #ifndef RT_HOST_BVH_H
 #define RT_HOST_BVH_H
 

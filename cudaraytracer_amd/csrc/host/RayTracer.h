@@ -34,6 +34,10 @@ class RayTracer {
     std::vector<std::unique_ptr<DeviceMesh>> meshes;
     int sceneBvhDepth = 0;
     BVH::BoundsMode boundsMode = BVH::REFERENCE_BOUNDS;  // applies to every BVH this driver builds
+    // upload() asks the library to recompute the boxes of the trees on the device (rt_set_upload_refit): with
+    // REFERENCE_BOUNDS the trees keep the reference's shape, leaf order and tie behaviour, and rays stop paying for its
+    // FLT_MIN-clamped boxes.  Set to false to walk the reference's boxes exactly as built.
+    bool refitAtUpload = true;
 
     explicit RayTracer(Options options, BVH::BoundsMode bounds = BVH::REFERENCE_BOUNDS) : options(options), boundsMode(bounds) {}
     RayTracer(const RayTracer&) = delete;
@@ -164,6 +168,7 @@ class RayTracer {
         std::vector<RtShape> shapeStore;
         std::vector<RtMesh> meshStore;
         const RtSceneDesc desc = currentScene().describe(shapeStore, meshStore);
+        check(rt_set_upload_refit(ctx, refitAtUpload ? 1 : 0), "rt_set_upload_refit");
         devScene = rt_scene_upload(ctx, &desc);
         if (!devScene) throw std::runtime_error(std::string("rt_scene_upload: ") + rt_last_error(ctx));
         check(rt_surface_create(ctx, options.device.width, options.device.height, &surface, &pitch), "rt_surface_create");

@@ -343,6 +343,91 @@ int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* streamPtr, int* degenerat
 }
 
 // ---------------------------------------------------------------------------
+// Bounds refit of a tree that is already in the blob (rt_set_upload_refit).  The reference's builder starts every box
+// union from an "empty" box whose max is FLT_MIN (cudaTracer/BoundingBox.cuh:25-27, cudaTracer/BVH.h:90-96), so every
+// box over negative coordinates reaches up to 0.  Topology, split axes and leaf contents stay as the caller built them;
+// only the boxes change: a mesh leaf gets the exact bounds of its triangles' vertex positions, an interior node the
+// exact union of its two children.  One thread per 32-byte record of the tree's pair array.
+namespace {
+__global__ void __launch_bounds__(kBlock) refitLeafKernel(uint32_t* __restrict__ pairs, uint32_t recCnt, const TriRecord* __restrict__ records,
+                                                          const unsigned char* __restrict__ vertices) {
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= recCnt || r == 1u) return;  // record 1 is the padding beside the root
+    uint32_t* rec = pairs + (size_t)r * 8;
+    const uint32_t ref = rec[6];
+    if (!RT_REF_IS_LEAF(ref)) return;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    const uint32_t first = RT_REF_LEAF_FIRST(ref), cnt = RT_REF_LEAF_COUNT(ref);
+    for (uint32_t t = first; t < first + cnt; ++t)
+        for (int c = 0; c < 3; ++c) {
+            const float* pos = reinterpret_cast<const float*>(vertices + (size_t)records[t].idx[c] * sizeof(RtVertex) + 44);
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = fminf(lo[a], pos[a]);
+                hi[a] = fmaxf(hi[a], pos[a]);
+            }
+        }
+    for (int a = 0; a < 3; ++a) {
+        rec[a] = __float_as_uint(lo[a]);
+        rec[3 + a] = __float_as_uint(hi[a]);
+    }
+}
+
+// The same for a BVH over shapes: a leaf gets the exact union of its shapes' own boxes (six floats per shape, in leaf
+// order), without the FLT_MIN the reference's builder unions into every leaf.
+__global__ void __launch_bounds__(kBlock) refitShapeLeafKernel(uint32_t* __restrict__ pairs, uint32_t recCnt, const float* __restrict__ shapeBoxes) {
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= recCnt || r == 1u) return;
+    uint32_t* rec = pairs + (size_t)r * 8;
+    const uint32_t ref = rec[6];
+    if (!RT_REF_IS_LEAF(ref)) return;
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    const uint32_t first = RT_REF_LEAF_FIRST(ref), cnt = RT_REF_LEAF_COUNT(ref);
+    for (uint32_t k = first; k < first + cnt; ++k)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = fminf(lo[a], shapeBoxes[6 * (size_t)k + a]);
+            hi[a] = fmaxf(hi[a], shapeBoxes[6 * (size_t)k + 3 + a]);
+        }
+    for (int a = 0; a < 3; ++a) {
+        rec[a] = __float_as_uint(lo[a]);
+        rec[3 + a] = __float_as_uint(hi[a]);
+    }
+}
+
+// One pass: every interior record takes the union of its children's CURRENT boxes.  After pass k every node of height
+// <= k is final (its children were final before the pass, and a child rewritten during the pass gets the same bits),
+// so `depth` passes settle the whole tree without level tables.
+__global__ void __launch_bounds__(kBlock) refitInteriorKernel(uint32_t* __restrict__ pairs, uint32_t pairBase, uint32_t recCnt) {
+    const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= recCnt || r == 1u) return;
+    uint32_t* rec = pairs + (size_t)r * 8;
+    const uint32_t ref = rec[6];
+    if (RT_REF_IS_LEAF(ref)) return;
+    const uint32_t pair = RT_REF_PAIR_UNITS(ref) - pairBase;
+    if (2u * pair + 1u >= recCnt) return;  // a reference that leaves the tree (the packer lets none through)
+    const float* c = reinterpret_cast<const float*>(pairs + (size_t)pair * 16);
+    for (int a = 0; a < 3; ++a) {
+        rec[a] = __float_as_uint(fminf(c[a], c[8 + a]));
+        rec[3 + a] = __float_as_uint(fmaxf(c[3 + a], c[8 + 3 + a]));
+    }
+}
+}  // namespace
+
+int rtk_refit_tree(void* pairs, uint32_t pairBase, uint32_t pairCnt, int depth, const void* records, const void* vertices, const float* shapeBoxes,
+                   void* stream) {
+    if (pairCnt == 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const uint32_t recCnt = 2u * pairCnt;
+    uint32_t* p = reinterpret_cast<uint32_t*>(pairs);
+    if (records && vertices)
+        hipLaunchKernelGGL(refitLeafKernel, dim3(blocksFor(recCnt)), dim3(kBlock), 0, s, p, recCnt, reinterpret_cast<const TriRecord*>(records),
+                           reinterpret_cast<const unsigned char*>(vertices));
+    else if (shapeBoxes)
+        hipLaunchKernelGGL(refitShapeLeafKernel, dim3(blocksFor(recCnt)), dim3(kBlock), 0, s, p, recCnt, shapeBoxes);
+    for (int pass = 0; pass < depth; ++pass) hipLaunchKernelGGL(refitInteriorKernel, dim3(blocksFor(recCnt)), dim3(kBlock), 0, s, p, pairBase, recCnt);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // Quad records (rt_device_format.h): one thread per half of a quad copies the child pair of one record of the pair,
 // or the record itself when it is a leaf, and turns the interior references it copies into references to quads.
 namespace {

@@ -6,7 +6,9 @@
 #include <hip/hip_vector_types.h>
 
 #include <algorithm>
+#include <cfloat>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -98,6 +100,7 @@ struct rt_ctx {
     bool accumFresh = false;    // a new accumulation: the next call clears the surface before it renders
     uint32_t overflowSeen = 0;  // overflow word of a workspace that was regrown before rt_sync could read it
     BuildParams bvhBuild;  // for meshes that arrive without BVH nodes
+    bool uploadRefit = false;  // rt_set_upload_refit: boxes of the trees a scene arrives with are recomputed from its geometry
     int tileOrderMode = RT_TILE_ORDER_CENTER_OUT;
     // tile orders already on the device, by (tile grid, shard, frame size); a table is never changed once made
     struct TileOrder {
@@ -179,7 +182,7 @@ hipError_t fillNow(void* dev, int value, size_t bytes, hipStream_t stream) {
 }
 
 // Levels below the root of a flattened tree; also validates child / primitive ranges.
-int treeDepth(const RtLinearNode* nodes, int nodeCnt, int primCnt, int* maxLeafPrims, std::string* err) {
+int treeDepth(const RtLinearNode* nodes, int nodeCnt, int primCnt, int* maxLeafPrims, std::string* err, bool checkBoxes = true) {
     struct Item {
         int idx, level;
     };
@@ -209,7 +212,7 @@ int treeDepth(const RtLinearNode* nodes, int nodeCnt, int primCnt, int* maxLeafP
             }
             // The walk over quads (rt_device_format.h) tests grandchildren without their parents: a node's box must hold
             // its children's boxes, as the exact union the reference's builder makes it (cudaTracer/BVH.h:90-96) does.
-            if (n.offset > it.idx && n.offset < nodeCnt)
+            if (checkBoxes && n.offset > it.idx && n.offset < nodeCnt)
                 for (int child : {it.idx + 1, (int)n.offset})
                     for (int k = 0; k < 3; ++k)
                         if (!(n.bbmin[k] <= nodes[child].bbmin[k] && nodes[child].bbmax[k] <= n.bbmax[k])) {
@@ -332,9 +335,47 @@ int staticTree(int n, int threshold, std::vector<RtLinearNode>& dfs, std::vector
     return idx;
 }
 
-// Flattens `desc` into a host blob.  Returns RT_OK or an error (message in *err).
+// Bounds refit on the host (rt_bvh_refit, and rt_scene_pack under rt_set_upload_refit): the same boxes, bit for bit, as
+// the device kernels of rt_bvh_build.hip produce.  `nodes` is a validated depth-first array, in which every child
+// sits behind its parent: one sweep from the back is bottom-up.
+void refitNodes(RtLinearNode* nodes, int nodeCnt, const RtVertex* vertices, const RtTriangle* triangles, const RtShape* shapes) {
+    for (int i = nodeCnt - 1; i >= 0; --i) {
+        RtLinearNode& n = nodes[i];
+        if (n.primCnt > 0) {
+            float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            for (int t = n.offset; t < n.offset + (int)n.primCnt; ++t) {
+                if (triangles) {
+                    for (int c = 0; c < 3; ++c) {
+                        const float* pos = vertices[triangles[t].i[c]].position;
+                        for (int a = 0; a < 3; ++a) {
+                            lo[a] = std::fmin(lo[a], pos[a]);
+                            hi[a] = std::fmax(hi[a], pos[a]);
+                        }
+                    }
+                } else {
+                    for (int a = 0; a < 3; ++a) {
+                        lo[a] = std::fmin(lo[a], shapes[t].bbmin[a]);
+                        hi[a] = std::fmax(hi[a], shapes[t].bbmax[a]);
+                    }
+                }
+            }
+            std::memcpy(n.bbmin, lo, sizeof lo);
+            std::memcpy(n.bbmax, hi, sizeof hi);
+        } else {
+            const RtLinearNode &a = nodes[i + 1], &b = nodes[n.offset];
+            for (int k = 0; k < 3; ++k) {
+                n.bbmin[k] = std::fmin(a.bbmin[k], b.bbmin[k]);
+                n.bbmax[k] = std::fmax(a.bbmax[k], b.bbmax[k]);
+            }
+        }
+    }
+}
+
+// Flattens `desc` into a host blob.  Returns RT_OK or an error (message in *err).  `refit`: the boxes of all trees
+// are recomputed from the geometry first (refitNodes); the caller's arrays are not touched.
 int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string* err, const BuildParams* build = nullptr,
-              std::vector<DeviceBuild>* builds = nullptr) {
+              std::vector<DeviceBuild>* builds = nullptr, bool refit = false, bool boxesWillBeRefit = false) {
+    const bool checkBoxes = !refit && !boxesWillBeRefit;  // a refit makes the boxes nest whatever they were
     auto bad = [&](const char* m) {
         *err = m;
         return RT_ERR_INVALID;
@@ -355,7 +396,7 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
     hd.sceneNodeCnt = d->nodeCnt;
 
     int maxLeafShapes = 0;
-    hd.sceneDepth = treeDepth(d->nodes, d->nodeCnt, d->shapeCnt, &maxLeafShapes, err);
+    hd.sceneDepth = treeDepth(d->nodes, d->nodeCnt, d->shapeCnt, &maxLeafShapes, err, checkBoxes);
     if (hd.sceneDepth < 0) return RT_ERR_INVALID;
     hd.maxLeafShapes = maxLeafShapes;
 
@@ -368,7 +409,14 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
     hd.offLights = reserve((size_t)std::max(d->lightCnt, 1) * sizeof(RtLight));
     hd.offShapes = reserve((size_t)d->shapeCnt * sizeof(DevShape));
     std::vector<RtLinearNode> scenePairs;
-    if (int r = pairLayout(d->nodes, scenePairs, RT_REF_SHAPES, err)) return r;
+    std::vector<RtLinearNode> refitted;  // a tree's nodes with recomputed boxes, while it is laid out
+    const RtLinearNode* sceneNodes = d->nodes;
+    if (refit) {
+        refitted.assign(d->nodes, d->nodes + d->nodeCnt);
+        refitNodes(refitted.data(), d->nodeCnt, nullptr, nullptr, d->shapes);
+        sceneNodes = refitted.data();
+    }
+    if (int r = pairLayout(sceneNodes, scenePairs, RT_REF_SHAPES, err)) return r;
     hd.offSceneNodes = reserve(scenePairs.size() * sizeof(RtLinearNode));
     hd.offMeshes = reserve((size_t)std::max(d->meshCnt, 1) * sizeof(DevMesh));
     // one record array for all meshes (+8 spare records), so that a leaf can name its triangles absolutely
@@ -407,7 +455,7 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
             for (const StaticNodeInfo& si : staticInfo) depth = std::max(depth, (int)si.level);
             recordOfNode.assign(staticNodes.size(), -1);
         } else {
-            depth = treeDepth(m.nodes, m.nodeCnt, m.triangleCnt, nullptr, err);
+            depth = treeDepth(m.nodes, m.nodeCnt, m.triangleCnt, nullptr, err, checkBoxes);
             if (depth < 0) return RT_ERR_INVALID;
         }
         hd.maxMeshDepth = std::max(hd.maxMeshDepth, depth);
@@ -415,7 +463,14 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
         dm.triangleCnt = m.triangleCnt;
         dm.nodeCnt = onDevice ? (int)staticNodes.size() : m.nodeCnt;
         dm.vertexCnt = m.vertexCnt;
-        if (int r = pairLayout(onDevice ? staticNodes.data() : m.nodes, meshPairs[mi], 0u, err, onDevice ? &recordOfNode : nullptr)) return r;
+        dm.depth = depth;
+        const RtLinearNode* meshNodes = onDevice ? staticNodes.data() : m.nodes;
+        if (refit && !onDevice) {
+            refitted.assign(m.nodes, m.nodes + m.nodeCnt);
+            refitNodes(refitted.data(), m.nodeCnt, m.vertices, m.triangles, nullptr);
+            meshNodes = refitted.data();
+        }
+        if (int r = pairLayout(meshNodes, meshPairs[mi], 0u, err, onDevice ? &recordOfNode : nullptr)) return r;
         dm.offNodes = reserve(meshPairs[mi].size() * sizeof(RtLinearNode));
         dm.recordBase = recordBase;
         dm.offTriRecords = hd.offRecords + (uint64_t)recordBase * sizeof(TriRecord);
@@ -850,7 +905,7 @@ int rt_scene_pack(rt_ctx* ctx, const RtSceneDesc* desc, void** blob, size_t* byt
     if (!blob || !bytes) return fail(ctx, RT_ERR_INVALID, "null output argument");
     std::vector<unsigned char> host;
     std::string err;
-    int r = packScene(desc, host, &err);
+    int r = packScene(desc, host, &err, nullptr, nullptr, ctx && ctx->uploadRefit);
     if (r != RT_OK) return fail(ctx, r, "%s", err.c_str());
     void* p = std::malloc(host.size());
     if (!p) return fail(ctx, RT_ERR_INVALID, "out of host memory");
@@ -895,6 +950,39 @@ int buildQuads(rt_ctx* ctx, rt_scene* sc) {
     RT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
+
+// rt_set_upload_refit: recomputes the boxes of the trees the scene arrived with, in the blob on the device (meshes whose
+// BVH was built on the device already have the boxes rt_set_device_bvh asked for).  `hostBlob` is the packed blob as
+// uploaded: its tables say where the trees are.
+int refitOnDevice(rt_ctx* ctx, rt_scene* sc, const unsigned char* hostBlob, const std::vector<DeviceBuild>& builds, const RtSceneDesc* desc) {
+    const BlobHeader& hd = sc->header;
+    auto pairsOf = [](int nodeCnt) { return (uint32_t)((nodeCnt + 1) / 2); };
+    const DevMesh* meshes = reinterpret_cast<const DevMesh*>(hostBlob + hd.offMeshes);
+    for (int mi = 0; mi < hd.meshCnt; ++mi) {
+        bool builtHere = false;
+        for (const DeviceBuild& b : builds) builtHere = builtHere || b.mesh == mi;
+        if (builtHere) continue;
+        const DevMesh& m = meshes[mi];
+        RT_HIP(ctx, (hipError_t)rtk_refit_tree(sc->blob + m.offNodes, (uint32_t)(m.offNodes / 64), pairsOf(m.nodeCnt), m.depth, sc->blob + hd.offRecords,
+                                                sc->blob + m.offVertices, nullptr, ctx->stream));
+    }
+    // the scene BVH's leaves: the shapes' own boxes, which the blob does not carry
+    std::vector<float> boxes(6 * (size_t)desc->shapeCnt);
+    for (int si = 0; si < desc->shapeCnt; ++si) {
+        std::memcpy(&boxes[6 * (size_t)si], desc->shapes[si].bbmin, 12);
+        std::memcpy(&boxes[6 * (size_t)si + 3], desc->shapes[si].bbmax, 12);
+    }
+    float* devBoxes = nullptr;
+    RT_HIP(ctx, hipMalloc((void**)&devBoxes, boxes.size() * sizeof(float)));
+    hipError_t e = uploadNow(devBoxes, boxes.data(), boxes.size() * sizeof(float), ctx->stream);
+    if (e == hipSuccess)
+        e = (hipError_t)rtk_refit_tree(sc->blob + hd.offSceneNodes, (uint32_t)(hd.offSceneNodes / 64), pairsOf(hd.sceneNodeCnt), hd.sceneDepth, nullptr, nullptr,
+                                       devBoxes, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(devBoxes);
+    if (e != hipSuccess) return fail(ctx, RT_ERR_DEVICE, "bounds refit on the device: %s", hipGetErrorString(e));
+    return RT_OK;
+}
 }  // namespace
 
 rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
@@ -905,7 +993,8 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
     const bool verbose = std::getenv("RT_TRACE_DEBUG") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
-    int r = packScene(desc, host, &err, &ctx->bvhBuild, &builds);
+    // with rt_set_upload_refit the blob is packed as it came and its boxes are recomputed on the device, below
+    int r = packScene(desc, host, &err, &ctx->bvhBuild, &builds, false, /*boxesWillBeRefit=*/ctx->uploadRefit);
     if (verbose) std::fprintf(stderr, "rt_scene_upload: packed %zu bytes in %.3f s\n", host.size(), now() - t0);
     if (r != RT_OK) {
         fail(ctx, r, "%s", err.c_str());
@@ -953,6 +1042,15 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
     sc->ownsBlob = true;
     sc->bytes = host.size();
     std::memcpy(&sc->header, host.data(), sizeof(BlobHeader));
+    if (ctx->uploadRefit) {
+        t0 = now();
+        const int rr = refitOnDevice(ctx, sc, host.data(), builds, desc);
+        if (verbose) std::fprintf(stderr, "rt_scene_upload: bounds refit on the device in %.3f s\n", now() - t0);
+        if (rr != RT_OK) {
+            rt_scene_free(sc);
+            return nullptr;
+        }
+    }
     if (buildQuads(ctx, sc) != RT_OK) {
         rt_scene_free(sc);
         return nullptr;
@@ -997,6 +1095,44 @@ int rt_set_device_bvh(rt_ctx* ctx, int threshold, int tightBounds) {
     if (threshold < 1 || threshold > RT_REF_MAX_LEAF_PRIMS) return fail(ctx, RT_ERR_INVALID, "leaf threshold must be in 1..%d", RT_REF_MAX_LEAF_PRIMS);
     ctx->bvhBuild.threshold = threshold;
     ctx->bvhBuild.tightBounds = tightBounds ? 1 : 0;
+    return RT_OK;
+}
+
+int rt_set_upload_refit(rt_ctx* ctx, int on) {
+    if (!ctx) return RT_ERR_INVALID;
+    ctx->uploadRefit = on != 0;
+    return RT_OK;
+}
+
+int rt_bvh_refit(RtLinearNode* nodes, int nodeCnt, const RtVertex* vertices, int vertexCnt, const RtTriangle* triangles, int triangleCnt) {
+    auto bad = [](const char* what) {
+        g_createError = what;
+        return RT_ERR_INVALID;
+    };
+    if (!nodes || nodeCnt < 1 || !vertices || !triangles || vertexCnt < 1 || triangleCnt < 1) return bad("rt_bvh_refit: null or empty argument");
+    std::string err;
+    if (treeDepth(nodes, nodeCnt, triangleCnt, nullptr, &err, false) < 0) {
+        g_createError = "rt_bvh_refit: " + err;
+        return RT_ERR_INVALID;
+    }
+    for (int t = 0; t < triangleCnt; ++t)
+        for (int c = 0; c < 3; ++c)
+            if (triangles[t].i[c] < 0 || triangles[t].i[c] >= vertexCnt) return bad("rt_bvh_refit: vertex index out of range");
+    refitNodes(nodes, nodeCnt, vertices, triangles, nullptr);
+    return RT_OK;
+}
+
+int rt_scene_bvh_refit(RtLinearNode* nodes, int nodeCnt, const RtShape* shapes, int shapeCnt) {
+    if (!nodes || nodeCnt < 1 || !shapes || shapeCnt < 1) {
+        g_createError = "rt_scene_bvh_refit: null or empty argument";
+        return RT_ERR_INVALID;
+    }
+    std::string err;
+    if (treeDepth(nodes, nodeCnt, shapeCnt, nullptr, &err, false) < 0) {
+        g_createError = "rt_scene_bvh_refit: " + err;
+        return RT_ERR_INVALID;
+    }
+    refitNodes(nodes, nodeCnt, nullptr, nullptr, shapes);
     return RT_OK;
 }
 

@@ -52,7 +52,7 @@
 #include "../../include/rt_capi.h"
 
 #define RT_BLOB_MAGIC 0x52544246u /* "RTBF" */
-#define RT_BLOB_VERSION 3u
+#define RT_BLOB_VERSION 4u
 #define RT_TILE 8 /* 8x8 pixels = 64 level-0 path nodes */
 #define RT_MESH_ENTRY_SLOTS 6 /* 8-byte slots per lane that hold the world-space ray while a mesh is walked */
 
@@ -126,7 +126,8 @@ struct DevMesh {
     int32_t vertexCnt;
     uint32_t rootRef;     // pseudo reference to the mesh BVH's root record
     uint32_t recordBase;  // index of the mesh's first triangle record in the blob's record array
-    int32_t pad[6];
+    int32_t depth;        // levels below the mesh BVH's root
+    int32_t pad[5];
 };
 
 // Triangle record, 48 bytes: v0 and the two edges exactly as the reference's
@@ -261,6 +262,15 @@ struct RtBvhBuildJob {
 // Runs the build on `stream` and waits for it.  Returns a hipError_t value; *degenerate is set when a range's
 // centroids all coincide (the reference makes such a range one big leaf; build that mesh on the host).
 int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* stream, int* degenerate);
+
+// Bounds refit of one BVH inside the blob (rt_set_upload_refit): `pairs` = device address of the tree's pair records,
+// `pairBase` = their blob offset / 64, `depth` = levels below the root.  A mesh BVH passes `records` (the blob's
+// triangle-record array) and `vertices` (the mesh's vertex array): its leaves get the exact bounds of their triangles.
+// The scene BVH passes `shapeBoxes` (device array, six floats {min, max} per shape in leaf order): its leaves get the
+// exact union of their shapes' boxes.  Interior boxes become the exact union of their children's.  Enqueued on
+// `stream`.  Returns a hipError_t value.
+int rtk_refit_tree(void* pairs, uint32_t pairBase, uint32_t pairCnt, int depth, const void* records, const void* vertices, const float* shapeBoxes,
+                   void* stream);
 
 // Quad records (see the head of this file) of one BVH: `pairs` = device address of the tree's pair records, `pairBase`
 // = their blob offset / 64 (what the references inside them count from), `pairCnt` pairs; quad i of the tree is written

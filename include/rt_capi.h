@@ -350,6 +350,24 @@ int rt_check_workspace_guards(rt_ctx* ctx);
  * a range into one leaf of any size); build that mesh's BVH on the host.  Defaults: threshold 10, tight bounds. */
 int rt_set_device_bvh(rt_ctx* ctx, int threshold, int tightBounds);
 
+/* Bounds refit at upload.  The reference's builder starts every box union from an "empty" box whose max is FLT_MIN
+ * (cudaTracer/BoundingBox.cuh:25-27 through cudaTracer/BVH.h:72-96), so each of its boxes over negative coordinates
+ * reaches up to 0: node arrays taken from the reference as they are (cudaTracer/CudaMesh.h:58-63) cost a ray 20-80 x
+ * the box and triangle tests of the same tree with true bounds.  With `on` != 0, rt_scene_upload recomputes the boxes
+ * of every tree a scene arrives with, on the device, before anything walks them: a mesh leaf gets the exact bounds of
+ * its triangles' vertex positions, a scene-BVH leaf the exact union of its shapes' own boxes (RtShape.bbmin / bbmax,
+ * as the caller computed them), an interior node the exact union of its children's boxes.  Topology, split axes,
+ * leaf contents and therefore visiting order and tie rule stay the caller's; hits are the same except for rays that
+ * lie exactly in a box face (a 0 x inf = NaN plane distance, whose outcome depends on which planes a box has).
+ * rt_scene_pack does the same on the host when given a context with the switch on, with the same bytes as result.
+ * Default: off (the reference's boxes are walked as they come).
+ * rt_bvh_refit / rt_scene_bvh_refit are the same computation on a caller's own node arrays, in place, host code only:
+ * for a mesh BVH (`triangles` in leaf order, as in RtMesh) and for the scene BVH (`shapes` in leaf order, as in
+ * RtSceneDesc).  Their errors: rt_last_error(NULL). */
+int rt_set_upload_refit(rt_ctx* ctx, int on);
+int rt_bvh_refit(RtLinearNode* nodes, int nodeCnt, const RtVertex* vertices, int vertexCnt, const RtTriangle* triangles, int triangleCnt);
+int rt_scene_bvh_refit(RtLinearNode* nodes, int nodeCnt, const RtShape* shapes, int shapeCnt);
+
 /* Mesh BVH built on the host, for callers that hand their meshes over WITH nodes (RtMesh.nodes).  Host code only: no
  * context, no GPU.  RT_BVH_MEDIAN_CUT is the reference's builder (cudaTracer/BVH.h:104-181, called with threshold 10
  * by cudaTracer/CudaMesh.h:58): same nodes, same leaf order.  RT_BVH_BINNED_SAH has no counterpart in the reference:
