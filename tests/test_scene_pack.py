@@ -64,7 +64,7 @@ def test_blob_holds_the_scene(rtlib, name, size, tight):
     h = header(blob)
     assert h["magic"] == 0x52544246 and h["totalBytes"] == len(blob) and len(blob) % 256 == 0
     assert (h["lightCnt"], h["shapeCnt"], h["meshCnt"], h["sceneNodeCnt"]) == (d.lightCnt, d.shapeCnt, d.meshCnt, d.nodeCnt)
-    assert h["version"] == 3 and h["recordCnt"] == sum(d.meshes[i].triangleCnt for i in range(d.meshCnt))
+    assert h["version"] == 4 and h["recordCnt"] == sum(d.meshes[i].triangleCnt for i in range(d.meshCnt))
     for k in ("offLights", "offShapes", "offSceneNodes", "offMeshes", "offRecords"):
         assert h[k] % 256 == 0 and h[k] < len(blob)
     # lights verbatim
