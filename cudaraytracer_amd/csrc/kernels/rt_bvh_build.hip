@@ -349,6 +349,11 @@ int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* streamPtr, int* degenerat
 // only the boxes change: a mesh leaf gets the exact bounds of its triangles' vertex positions, an interior node the
 // exact union of its two children.  One thread per 32-byte record of the tree's pair array.
 namespace {
+// Written as comparisons, like the host side (rt_capi.cpp refitNodes), so that both keep the value seen first when
+// +0 meets -0 and the two refits agree bit for bit (fmin / fmax may pick either zero).
+__device__ __forceinline__ float refitMin(float acc, float x) { return x < acc ? x : acc; }
+__device__ __forceinline__ float refitMax(float acc, float x) { return x > acc ? x : acc; }
+
 __global__ void __launch_bounds__(kBlock) refitLeafKernel(uint32_t* __restrict__ pairs, uint32_t recCnt, const TriRecord* __restrict__ records,
                                                           const unsigned char* __restrict__ vertices) {
     const uint32_t r = blockIdx.x * kBlock + threadIdx.x;
@@ -362,8 +367,8 @@ __global__ void __launch_bounds__(kBlock) refitLeafKernel(uint32_t* __restrict__
         for (int c = 0; c < 3; ++c) {
             const float* pos = reinterpret_cast<const float*>(vertices + (size_t)records[t].idx[c] * sizeof(RtVertex) + 44);
             for (int a = 0; a < 3; ++a) {
-                lo[a] = fminf(lo[a], pos[a]);
-                hi[a] = fmaxf(hi[a], pos[a]);
+                lo[a] = refitMin(lo[a], pos[a]);
+                hi[a] = refitMax(hi[a], pos[a]);
             }
         }
     for (int a = 0; a < 3; ++a) {
@@ -384,8 +389,8 @@ __global__ void __launch_bounds__(kBlock) refitShapeLeafKernel(uint32_t* __restr
     const uint32_t first = RT_REF_LEAF_FIRST(ref), cnt = RT_REF_LEAF_COUNT(ref);
     for (uint32_t k = first; k < first + cnt; ++k)
         for (int a = 0; a < 3; ++a) {
-            lo[a] = fminf(lo[a], shapeBoxes[6 * (size_t)k + a]);
-            hi[a] = fmaxf(hi[a], shapeBoxes[6 * (size_t)k + 3 + a]);
+            lo[a] = refitMin(lo[a], shapeBoxes[6 * (size_t)k + a]);
+            hi[a] = refitMax(hi[a], shapeBoxes[6 * (size_t)k + 3 + a]);
         }
     for (int a = 0; a < 3; ++a) {
         rec[a] = __float_as_uint(lo[a]);
@@ -406,8 +411,8 @@ __global__ void __launch_bounds__(kBlock) refitInteriorKernel(uint32_t* __restri
     if (2u * pair + 1u >= recCnt) return;  // a reference that leaves the tree (the packer lets none through)
     const float* c = reinterpret_cast<const float*>(pairs + (size_t)pair * 16);
     for (int a = 0; a < 3; ++a) {
-        rec[a] = __float_as_uint(fminf(c[a], c[8 + a]));
-        rec[3 + a] = __float_as_uint(fmaxf(c[3 + a], c[8 + 3 + a]));
+        rec[a] = __float_as_uint(refitMin(c[a], c[8 + a]));
+        rec[3 + a] = __float_as_uint(refitMax(c[3 + a], c[8 + 3 + a]));
     }
 }
 }  // namespace

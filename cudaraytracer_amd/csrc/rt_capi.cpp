@@ -338,6 +338,9 @@ int staticTree(int n, int threshold, std::vector<RtLinearNode>& dfs, std::vector
 // Bounds refit on the host (rt_bvh_refit, and rt_scene_pack under rt_set_upload_refit): the same boxes, bit for bit, as
 // the device kernels of rt_bvh_build.hip produce.  `nodes` is a validated depth-first array, in which every child
 // sits behind its parent: one sweep from the back is bottom-up.
+// (minimum / maximum as comparisons: of +0 and -0 the one seen first stays, on the host as on the device)
+inline float refitMin(float acc, float x) { return x < acc ? x : acc; }
+inline float refitMax(float acc, float x) { return x > acc ? x : acc; }
 void refitNodes(RtLinearNode* nodes, int nodeCnt, const RtVertex* vertices, const RtTriangle* triangles, const RtShape* shapes) {
     for (int i = nodeCnt - 1; i >= 0; --i) {
         RtLinearNode& n = nodes[i];
@@ -348,14 +351,14 @@ void refitNodes(RtLinearNode* nodes, int nodeCnt, const RtVertex* vertices, cons
                     for (int c = 0; c < 3; ++c) {
                         const float* pos = vertices[triangles[t].i[c]].position;
                         for (int a = 0; a < 3; ++a) {
-                            lo[a] = std::fmin(lo[a], pos[a]);
-                            hi[a] = std::fmax(hi[a], pos[a]);
+                            lo[a] = refitMin(lo[a], pos[a]);
+                            hi[a] = refitMax(hi[a], pos[a]);
                         }
                     }
                 } else {
                     for (int a = 0; a < 3; ++a) {
-                        lo[a] = std::fmin(lo[a], shapes[t].bbmin[a]);
-                        hi[a] = std::fmax(hi[a], shapes[t].bbmax[a]);
+                        lo[a] = refitMin(lo[a], shapes[t].bbmin[a]);
+                        hi[a] = refitMax(hi[a], shapes[t].bbmax[a]);
                     }
                 }
             }
@@ -364,8 +367,8 @@ void refitNodes(RtLinearNode* nodes, int nodeCnt, const RtVertex* vertices, cons
         } else {
             const RtLinearNode &a = nodes[i + 1], &b = nodes[n.offset];
             for (int k = 0; k < 3; ++k) {
-                n.bbmin[k] = std::fmin(a.bbmin[k], b.bbmin[k]);
-                n.bbmax[k] = std::fmax(a.bbmax[k], b.bbmax[k]);
+                n.bbmin[k] = refitMin(a.bbmin[k], b.bbmin[k]);
+                n.bbmax[k] = refitMax(a.bbmax[k], b.bbmax[k]);
             }
         }
     }

@@ -31,7 +31,8 @@ def test_reference_nodes_refit_at_upload(refit_ctx, gpu_ctx, oracle, rtlib, synt
     ptr, n = refit_ctx.scene_blob(dscene)
     dev_blob = refit_ctx.download(ptr, (n,), np.uint8)
     host_blob = refit_ctx.pack(scene.desc)
-    assert np.array_equal(dev_blob, host_blob), "device refit and host refit disagree"
+    differing = np.flatnonzero(dev_blob != host_blob)
+    assert differing.size == 0, f"device refit and host refit disagree in {differing.size} bytes, first at offset {differing[:8]}"
     assert not np.array_equal(host_blob, gpu_ctx.pack(scene.desc))  # and the refit did change boxes
     rgba, keys, cnt = refit_ctx.render_frame(scene, dscene, want_keys=True, want_counters=True)
     plain = refit_ctx.render_frame(scene, dscene, want_keys=True)  # the walk over quads, built from the refitted pairs
