@@ -185,14 +185,21 @@ def time_frames(ctx, render, frames, in_flight, surfaces):
 
 
 def other_workload(ctx, torch, dev, label, scene_args, scene_kwargs, nf):
-    """In-order and in-flight figures of another workload of the scope table, on the same kernels."""
+    """In-order and in-flight figures of another workload of the scope table, on the same kernels.
+    scene_kwargs["upload_refit"]: upload with rt_set_upload_refit on (boxes recomputed on the device)."""
+    scene_kwargs = dict(scene_kwargs)
+    refit = scene_kwargs.pop("upload_refit", False)
     t0 = time.perf_counter()
     scene = rt.HostScene(*scene_args, **scene_kwargs)
     build_s = time.perf_counter() - t0
     w, h = scene.width, scene.height
+    ctx.set_upload_refit(refit)
     t0 = time.perf_counter()
-    dscene = ctx.upload(scene)
-    ctx.sync()
+    try:
+        dscene = ctx.upload(scene)
+        ctx.sync()
+    finally:
+        ctx.set_upload_refit(False)
     upload_s = time.perf_counter() - t0
     surfaces = [torch.zeros((h, w, 4), dtype=torch.float32, device=dev) for _ in range(nf)]
     pitch = w * 16
@@ -216,6 +223,30 @@ def other_workload(ctx, torch, dev, label, scene_args, scene_kwargs, nf):
             "in_order_ms_per_frame": ev1[0], "in_order_Mrays_per_s": rays / wall1 / 1e3,
             "in_flight_ms_per_frame": walln, "in_flight_Mrays_per_s": rays / walln / 1e3, "frames_in_flight": nf,
             "scene_build_s": round(build_s, 2), "upload_s": round(upload_s, 2)}
+
+
+def default_queue_run(args, nf):
+    """The headline's timed region again in a child process that leaves GPU_MAX_HW_QUEUES at HIP's default of 4 (the
+    variable is read once, at the process's first HIP call, so one process cannot measure both): what a caller gets
+    who asks for frames in flight and sets nothing else."""
+    import subprocess
+
+    env = dict(os.environ)
+    env["RT_BENCH_HW_QUEUES"] = "4"
+    steps = max(args.steps // 2, 20)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(args.warmup), "--no-others", "--no-cpu",
+           "--scene", args.scene, "--size", str(args.size), "--width", str(args.width), "--height", str(args.height), "--lights", str(args.lights),
+           "--max-depth", str(args.max_depth), "--bvh", args.bvh, "--frames-in-flight", str(nf)] + (["--reference-bvh"] if args.reference_bvh else [])
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+        child = json.loads(line)
+        return {"GPU_MAX_HW_QUEUES": 4, "value": child["value"], "unit": child["unit"], "ms_per_step": child["ms_per_step"], "steps": steps,
+                "frames_in_flight": nf, "in_order_Mrays_per_s": child["config"]["in_order"]["Mrays_per_s"],
+                "note": "same workload and timed region in a child process with HIP's default number of hardware queues; `value` above ran with "
+                        f"GPU_MAX_HW_QUEUES={os.environ['GPU_MAX_HW_QUEUES']}"}
+    except Exception as e:  # reported, the headline stays
+        return {"GPU_MAX_HW_QUEUES": 4, "error": f"{type(e).__name__}: {e}"}
 
 
 class mg_single:
@@ -446,6 +477,10 @@ def main():
              ("soup", w, h, args.size, args.lights, args.max_depth), {"tight_bvh": True}),
             ("cfg 2 on the reference's own BVH: the same soup with FLT_MIN-clamped boxes (cudaTracer/BoundingBox.cuh:25-27)",
              ("soup", w, h, args.size, args.lights, args.max_depth), {"tight_bvh": False}),
+            ("cfg 2 on the reference's own BVH with the boxes recomputed at upload (rt_set_upload_refit): the reference's tree shape, leaf order "
+             "and ties, true bounds; its cuts were made on FLT_MIN-clamped centroid bounds (cudaTracer/BVH.h:122-128), so it stays behind a tree "
+             "built on true bounds",
+             ("soup", w, h, args.size, args.lights, args.max_depth), {"tight_bvh": False, "upload_refit": True}),
             ("cfg 1: 16x16 grid of cube meshes (one mesh BVH each) under a scene BVH, 640x480, 4 lights, maxDepth 5",
              ("cubes", 640, 480, 16, 4, 5), {"tight_bvh": True}),
             ("cfg 3: OBJ barrel (488 triangles, three 1024x1024 maps) in three instances, one a mirror, textured plane, mirror and "
@@ -464,6 +499,8 @@ def main():
                 others.append(other_workload(ctx, torch, dev, label, a, kw, nf))
             except Exception as e:  # a workload that cannot run is reported, the headline stays
                 others.append({"workload": label, "error": str(e)})
+
+    default_queues = default_queue_run(args, nf) if (rank == 0 and not multi and not args.no_others) else None
 
     frame_ms, closest_ms, shade_ms, shadow_ms, rest_ms = alone_stage
     if rank == 0:
@@ -515,6 +552,8 @@ def main():
                        "in_order": {"ms_per_frame": frame_ms, "wall_ms_per_frame": alone_wall, "Mrays_per_s": rays / alone_wall / 1e3,
                                     "note": "one frame in flight: every frame starts after the previous one has finished, as the reference's "
                                             "cudamain + cudaDeviceSynchronize does; `value` overlaps consecutive frames instead"},
+                       "default_hw_queues": default_queues,
+                       "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                        "gathered_frame": gather_check,
                        "scene_build_s": round(t_build, 2),
                        "other_workloads": others},

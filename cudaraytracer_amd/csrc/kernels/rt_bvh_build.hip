@@ -19,9 +19,12 @@
 // whenever the median value is unique, so node boxes and axes are those of the
 // host builder, while the order inside a leaf may differ.
 //
-// Not reproduced: the reference turns a range whose centroids all coincide into
-// a leaf of any size (cudaTracer/BVH.h:126-128).  The device build reports such
-// a mesh instead (the caller falls back to the host builder).
+// Equal centroid coordinates: the sort is stable, so primitives whose keys tie keep the order they had (at first,
+// the caller's order); the cut then falls between two equal keys, as it may with any nth_element.  Not reproduced:
+// the reference turns a range whose centroids ALL coincide into a leaf of any size (cudaTracer/BVH.h:126-128).  Here
+// such a range keeps its order and is cut at the median position like any other (split axis Z by the tie rule), so
+// the tree keeps the shape the count dictates; the boxes are right either way, and only ties between primitives
+// with identical box centroids can resolve differently.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <float.h>
@@ -158,7 +161,7 @@ __global__ void __launch_bounds__(kBlock) centroidBoundsKernel(int n, int thresh
 __global__ void __launch_bounds__(kBlock) sortKeyKernel(int n, int threshold, int level, const uint32_t* __restrict__ order,
                                                         const float4* __restrict__ bmin, const float4* __restrict__ bmax,
                                                         const uint32_t* __restrict__ cb, unsigned char* __restrict__ axisOut,
-                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ flags) {
+                                                        uint64_t* __restrict__ keys) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     int s, e;
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__(kBlock) sortKeyKernel(int n, int threshold, in
     // BoundingBox::maxExtent
     const float d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
     const int dim = (d0 > d1 && d0 > d2) ? 0 : (d1 > d2 ? 1 : 2);
-    if (hi[dim] == lo[dim]) atomicOr(flags, 1u);  // all centroids coincide: the reference makes this a leaf
+    // (hi[dim] == lo[dim]: all centroids coincide, every key of the range ties and the range keeps its order)
     if (i == s) axisOut[id - 1u] = (unsigned char)dim;
     const uint32_t prim = order[i];
     float c[3];
@@ -275,18 +278,17 @@ static_assert(sizeof(BuildNode) == sizeof(RtBuildNode), "host and device agree o
         }                                  \
     } while (0)
 
-int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* streamPtr, int* degenerate) {
+int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* streamPtr) {
     hipStream_t stream = reinterpret_cast<hipStream_t>(streamPtr);
     const int n = job->triangleCnt, thr = job->threshold, tight = job->tightBounds;
-    *degenerate = 0;
     float4 *bmin = nullptr, *bmax = nullptr;
-    uint32_t *orderA = nullptr, *orderB = nullptr, *cb = nullptr, *flags = nullptr;
+    uint32_t *orderA = nullptr, *orderB = nullptr, *cb = nullptr;
     uint64_t *keysA = nullptr, *keysB = nullptr;
     unsigned char* axisOf = nullptr;
     void* temp = nullptr;
     BuildNode* nodes = nullptr;
     auto cleanup = [&]() {
-        void* all[] = {bmin, bmax, orderA, orderB, cb, flags, keysA, keysB, axisOf, temp, nodes};
+        void* all[] = {bmin, bmax, orderA, orderB, cb, keysA, keysB, axisOf, temp, nodes};
         for (void* p : all)
             if (p) (void)hipFree(p);
     };
@@ -299,9 +301,7 @@ int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* streamPtr, int* degenerat
     RTB_HIP(hipMalloc(&keysB, (size_t)n * 8));
     RTB_HIP(hipMalloc(&cb, heap * 6 * 4));
     RTB_HIP(hipMalloc(&axisOf, heap));
-    RTB_HIP(hipMalloc(&flags, 4));
     RTB_HIP(hipMalloc(&nodes, (size_t)job->nodeCnt * sizeof(BuildNode)));
-    RTB_HIP(hipMemsetAsync(flags, 0, 4, stream));
     RTB_HIP(hipMemsetAsync(axisOf, 0, heap, stream));
     RTB_HIP(hipMemcpyAsync(nodes, job->nodes, (size_t)job->nodeCnt * sizeof(BuildNode), hipMemcpyHostToDevice, stream));
     size_t tempBytes = 0;
@@ -315,7 +315,7 @@ int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* streamPtr, int* degenerat
         const uint32_t first = (1u << level) - 1u, count = 1u << level;
         hipLaunchKernelGGL(boundsInitKernel, dim3(blocksFor(count)), dim3(kBlock), 0, stream, first, count, tight, cb);
         hipLaunchKernelGGL(centroidBoundsKernel, dim3(grid), dim3(kBlock), 0, stream, n, thr, level, orderA, bmin, bmax, cb);
-        hipLaunchKernelGGL(sortKeyKernel, dim3(grid), dim3(kBlock), 0, stream, n, thr, level, orderA, bmin, bmax, cb, axisOf, keysA, flags);
+        hipLaunchKernelGGL(sortKeyKernel, dim3(grid), dim3(kBlock), 0, stream, n, thr, level, orderA, bmin, bmax, cb, axisOf, keysA);
         // range ids of this level need level + 1 bits above the 32-bit coordinate
         RTB_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, keysA, keysB, orderA, orderB, n, 0, 32 + level + 1, stream));
         uint32_t* t = orderA;
@@ -333,11 +333,8 @@ int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* streamPtr, int* degenerat
     }
     hipLaunchKernelGGL(recordKernel, dim3(grid), dim3(kBlock), 0, stream, n, thr, orderA, job->devTriangles, job->devVertices,
                        reinterpret_cast<TriRecord*>(job->devTriRecords));
-    uint32_t hostFlags = 0;
-    RTB_HIP(hipMemcpyAsync(&hostFlags, flags, 4, hipMemcpyDeviceToHost, stream));
     RTB_HIP(hipStreamSynchronize(stream));
     RTB_HIP(hipGetLastError());
-    *degenerate = (int)(hostFlags & 1u);
     cleanup();
     return 0;
 }

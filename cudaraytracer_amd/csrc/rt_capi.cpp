@@ -1018,7 +1018,6 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
         int32_t* devTris = nullptr;
         e = hipMalloc((void**)&devTris, (size_t)m.triangleCnt * sizeof(RtTriangle));
         if (e == hipSuccess) e = uploadNow(devTris, m.triangles, (size_t)m.triangleCnt * sizeof(RtTriangle), ctx->stream);
-        int degenerate = 0;
         if (e == hipSuccess) {
             b.job.nodes = b.table.data();
             b.job.devTriangles = devTris;
@@ -1026,15 +1025,12 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
             b.job.devNodeRecords = dev + b.offNodes;
             b.job.devTriRecords = dev + b.offRecords;
             t0 = now();
-            e = (hipError_t)rtk_build_mesh_bvh(&b.job, ctx->stream, &degenerate);
+            e = (hipError_t)rtk_build_mesh_bvh(&b.job, ctx->stream);
             if (verbose) std::fprintf(stderr, "rt_scene_upload: BVH of mesh %d (%d triangles) built on the device in %.3f s\n", b.mesh, m.triangleCnt, now() - t0);
         }
         if (devTris) hipFree(devTris);
-        if (e != hipSuccess || degenerate) {
-            if (e != hipSuccess)
-                fail(ctx, RT_ERR_DEVICE, "BVH build of mesh %d on the device: %s", b.mesh, hipGetErrorString(e));
-            else
-                fail(ctx, RT_ERR_INVALID, "mesh %d has a range of triangles whose box centroids all coincide; build its BVH on the host", b.mesh);
+        if (e != hipSuccess) {
+            fail(ctx, RT_ERR_DEVICE, "BVH build of mesh %d on the device: %s", b.mesh, hipGetErrorString(e));
             hipFree(dev);
             return nullptr;
         }

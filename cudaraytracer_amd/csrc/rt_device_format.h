@@ -259,9 +259,8 @@ struct RtBvhBuildJob {
     unsigned char* devNodeRecords;      // the mesh's node records (references already in place)
     unsigned char* devTriRecords;       // the mesh's triangle records
 };
-// Runs the build on `stream` and waits for it.  Returns a hipError_t value; *degenerate is set when a range's
-// centroids all coincide (the reference makes such a range one big leaf; build that mesh on the host).
-int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* stream, int* degenerate);
+// Runs the build on `stream` and waits for it.  Returns a hipError_t value.
+int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* stream);
 
 // Bounds refit of one BVH inside the blob (rt_set_upload_refit): `pairs` = device address of the tree's pair records,
 // `pairBase` = their blob offset / 64, `depth` = levels below the root.  A mesh BVH passes `records` (the blob's

@@ -343,11 +343,13 @@ int rt_check_workspace_guards(rt_ctx* ctx);
  * BVH built on the GPU with the algorithm of cudaTracer/BVH.h:104-181 (median cut of the box centroids along the
  * widest axis of the centroid bounds, leaves of at most `threshold` triangles; the reference uses 10,
  * cudaTracer/CudaMesh.h:58): same tree shape, boxes and split axes as the host builder whenever the median
- * centroids are distinct; the order of triangles inside a leaf may differ.  `tightBounds` = 0 starts boxes from
- * the reference's (FLT_MAX, FLT_MIN) empty box (cudaTracer/BoundingBox.cuh:25-27), 1 from a true empty box.
- * The triangles of such a mesh are given in any order; rt_scene_pack (host only) rejects it.  A mesh in which
- * some range of triangles has coinciding box centroids is rejected with RT_ERR_INVALID (the reference turns such
- * a range into one leaf of any size); build that mesh's BVH on the host.  Defaults: threshold 10, tight bounds. */
+ * centroids are distinct; the order of triangles inside a leaf may differ.  Where centroid coordinates tie at a cut
+ * (grids, cubes), the tied triangles go left and right in the order the caller gave them - a deterministic choice
+ * among those std::nth_element may make - and a range whose box centroids ALL coincide, which the reference turns
+ * into one leaf of any size (cudaTracer/BVH.h:126-128), is cut at its median position like any other range: same
+ * hits, except equal-distance ties among such triangles.  `tightBounds` = 0 starts boxes from the reference's
+ * (FLT_MAX, FLT_MIN) empty box (cudaTracer/BoundingBox.cuh:25-27), 1 from a true empty box.  The triangles of such a
+ * mesh are given in any order; rt_scene_pack (host only) rejects it.  Defaults: threshold 10, tight bounds. */
 int rt_set_device_bvh(rt_ctx* ctx, int threshold, int tightBounds);
 
 /* Bounds refit at upload.  The reference's builder starts every box union from an "empty" box whose max is FLT_MIN

@@ -30,12 +30,13 @@ class Mesh:
     else a list of (bbmin, bbmax, offset, primCnt, axis) in the reference's depth-first order."""
 
     def __init__(self, triangles, material=DIFFUSE, ior=1.3, ks=0.0, spec_exp=25.0, diffuse=WHITE, specular=BLACK, normals=FLAT_NORMAL,
-                 nodes=None, mode=1, transform_inverse=None, world_box=None):
+                 nodes=None, mode=1, transform_inverse=None, world_box=None, device_bvh=False):
         self.triangles, self.material, self.ior, self.ks, self.spec_exp = triangles, material, ior, ks, spec_exp
         self.maps = (diffuse, normals, specular)
         self.nodes, self.mode = nodes, mode
         # row-major, row-vector convention (cudaTracer/Mat.cuh:127-149); with it, world_box = (min, max) of the shape
         self.transform_inverse, self.world_box = transform_inverse, world_box
+        self.device_bvh = device_bvh  # no nodes at all: rt_scene_upload builds the BVH on the GPU
 
 
 def tri(p0, p1, p2, uv=((0, 0), (1, 0), (0, 1)), normal=(0, 0, -1)):
@@ -74,6 +75,8 @@ class Scene:
             dm = self.meshes[mi]
             dm.triangleCnt, dm.triangles, dm.vertexCnt, dm.vertices = nt, tris, 3 * nt, verts
             dm.nodeCnt, dm.nodes = len(spec), nodes
+            if m.device_bvh:
+                dm.nodeCnt, dm.nodes = 0, None
             for name, px in zip(("diffuse", "normals", "specular"), m.maps):
                 tex, buf = texture(px, m.mode)
                 setattr(dm, name, tex)

@@ -156,3 +156,42 @@ def test_other_leaf_sizes(gpu_ctx, oracle):
             gpu_ctx.set_device_bvh(64, True)
     finally:
         gpu_ctx.set_device_bvh(10, True)
+
+
+def test_ranges_of_coinciding_centroids_build_on_the_device(gpu_ctx, oracle, rtlib):
+    """Triangles whose boxes - hence box centroids - coincide: the reference's builder stops at such a range and makes
+    it one leaf of any size (cudaTracer/BVH.h:126-128); the device build cuts it at the median position.  Same hits:
+    the frame of the device-built tree equals the oracle's on the host-built one."""
+    import hand_scenes as hs
+    from test_gpu_fuzz import bvh_of
+
+    rng = np.random.default_rng(5)
+    tris = []
+    for c in ((-1.5, 0.0, 6.0), (1.5, 0.5, 7.0), (0.0, -1.0, 9.0)):
+        c = np.float32(c)
+        for k in range(25):  # 25 triangles per clump, all with the box [c - 1, c + 1]: each touches all six faces
+            a, b = rng.uniform(-1, 1, 2)
+            p = np.float32([[-1, a, -1], [1, -1, b], [b, 1, 1]]) + c
+            if np.cross(p[1] - p[0], p[2] - p[0])[2] > 0:
+                p = p[[0, 2, 1]]
+            tris.append(hs.tri(*[tuple(float(x) for x in v) for v in p]))
+    for k in range(40):  # and some ordinary ones around them
+        c = rng.uniform(-3, 3, 3) + np.float32([0, 0, 8])
+        p = np.float32(c + rng.uniform(-0.7, 0.7, (3, 3)))
+        if np.cross(p[1] - p[0], p[2] - p[0])[2] > 0:
+            p = p[[0, 2, 1]]
+        tris.append(hs.tri(*[tuple(float(x) for x in v) for v in p]))
+    lights = [((0, 4, 0), (1, 1, 1), 8.0), ((3, 0, 2), (1, 1, 1), 5.0)]
+    w, h = 96, 64
+    # the oracle walks the host builder's tree, whose clumps are single leaves of 25
+    ordered, spec = bvh_of(rtlib, tris, 0, 10, 1)
+    assert max(n[3] for n in spec) == 25
+    host_scene = hs.Scene(w, h, [hs.Mesh(ordered, nodes=spec)], lights=lights)
+    ref_rgba, ref_keys = host_scene.render_oracle(oracle)
+    # hand_scenes numbers a triangle's vertices by its position in the list: give both scenes the leaf-ordered list
+    dev_scene = hs.Scene(w, h, [hs.Mesh(ordered, device_bvh=True)], lights=lights)
+    gpu_ctx.set_device_bvh(10, True)
+    rgba, keys = dev_scene.render_gpu(gpu_ctx)
+    assert (ref_keys[..., 0] == 0).mean() > 0.2
+    assert np.array_equal(keys, ref_keys)
+    assert np.array_equal(rgba, ref_rgba, equal_nan=True)
