@@ -5,4 +5,4 @@ host API's harness; all rendering happens in the HIP kernels.
 """
 from ._native import (RT_COUNTER_CNT, RT_COUNTER_NAMES, RtCamera, RtDeviceOpts, RtFrameAux, RtLight, RtSceneDesc,  # noqa: F401
                       load)
-from .api import Context, Experiment, HostScene, RtError, pack_scene, tiles_of_rank  # noqa: F401
+from .api import Context, Experiment, HostScene, MultiContext, RtError, pack_scene, tiles_of_rank  # noqa: F401

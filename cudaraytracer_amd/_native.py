@@ -129,6 +129,20 @@ C_ABI = {
     "rt_set_accumulation": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32]),
     "rt_set_workspace_guards": (C.c_int, [C.c_void_p, C.c_size_t]),
     "rt_check_workspace_guards": (C.c_int, [C.c_void_p]),
+    "rt_tiles_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "rt_tiles_scatter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]),
+    "rt_multi_create": (C.c_void_p, [C.c_int, C.POINTER(C.c_int)]),
+    "rt_multi_destroy": (None, [C.c_void_p]),
+    "rt_multi_last_error": (C.c_char_p, [C.c_void_p]),
+    "rt_multi_device_count": (C.c_int, [C.c_void_p]),
+    "rt_multi_context": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "rt_multi_scene_upload": (C.c_int, [C.c_void_p, C.POINTER(RtSceneDesc)]),
+    "rt_multi_scene_set_lights": (C.c_int, [C.c_void_p, C.POINTER(RtLight), C.c_int]),
+    "rt_multi_balance": (C.c_int, [C.c_void_p, C.POINTER(RtDeviceOpts), C.POINTER(RtCamera)]),
+    "rt_multi_tile_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    "rt_multi_set_quantize": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_multi_render": (C.c_int, [C.c_void_p, C.POINTER(RtDeviceOpts), C.POINTER(RtCamera), C.c_void_p, C.c_size_t, C.c_int]),
+    "rt_multi_sync": (C.c_int, [C.c_void_p]),
 }
 
 HARNESS = {

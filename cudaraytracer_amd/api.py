@@ -386,3 +386,88 @@ class Context:
                 self.free(cnt)
             if own:
                 self.free_scene(scene)
+
+
+class MultiContext:
+    """Several GPUs driven from this one process (rt_multi_* of the C-ABI): the scene uploaded once and copied to the
+    peers, every device rendering its own tiles of the same frame, the tiles gathered into a surface on devices[0].
+    A device may be named more than once (several contexts on one GPU)."""
+
+    def __init__(self, devices):
+        self.lib = N.load()
+        arr = (C.c_int * len(devices))(*devices)
+        self.m = self.lib.rt_multi_create(len(devices), arr)
+        if not self.m:
+            raise RtError("rt_multi_create: " + self.lib.rt_multi_last_error(None).decode())
+        self.ndev = len(devices)
+        self._allocs = []
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RtError(f"{what} failed ({rc}): {self.lib.rt_multi_last_error(self.m).decode()}")
+
+    def _check0(self, rc, what):
+        if rc != 0:
+            raise RtError(f"{what} failed ({rc}): {self.lib.rt_last_error(self.raw_context(0)).decode()}")
+
+    def raw_context(self, i):
+        """The i-th device's rt_ctx* (for the per-context knobs, e.g. lib.rt_set_upload_refit(raw_context(0), 1))."""
+        return self.lib.rt_multi_context(self.m, i)
+
+    def close(self):
+        if not self.m:
+            return
+        for p in self._allocs:
+            self.lib.rt_device_free(self.raw_context(0), p)
+        self._allocs = []
+        self.lib.rt_multi_destroy(self.m)
+        self.m = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def upload(self, scene_or_desc):
+        desc = scene_or_desc.desc if isinstance(scene_or_desc, HostScene) else scene_or_desc
+        self._check(self.lib.rt_multi_scene_upload(self.m, desc), "rt_multi_scene_upload")
+
+    def set_lights(self, desc):
+        d = desc.contents if hasattr(desc, "contents") else desc
+        self._check(self.lib.rt_multi_scene_set_lights(self.m, d.lights, d.lightCnt), "rt_multi_scene_set_lights")
+
+    def balance(self, opts, camera):
+        o = opts.contents if hasattr(opts, "contents") else opts
+        self._check(self.lib.rt_multi_balance(self.m, C.byref(o), camera), "rt_multi_balance")
+
+    def tile_counts(self):
+        out = (C.c_int * self.ndev)()
+        self._check(self.lib.rt_multi_tile_counts(self.m, out), "rt_multi_tile_counts")
+        return list(out)
+
+    def set_quantize(self, on):
+        self._check(self.lib.rt_multi_set_quantize(self.m, 1 if on else 0), "rt_multi_set_quantize")
+
+    def surface(self, width, height, bytes_per_pixel=16):
+        """A surface on devices[0]: float4 pixels (16) or 8-bit RGBA (4).  Returns (pointer, pitch)."""
+        p = C.c_void_p()
+        pitch = (width * bytes_per_pixel + 255) // 256 * 256
+        self._check0(self.lib.rt_device_alloc(self.raw_context(0), pitch * height, C.byref(p)), "rt_device_alloc")
+        self._allocs.append(p.value)
+        return p.value, pitch
+
+    def download(self, ptr, pitch, width, height, bytes_per_pixel=16):
+        raw = np.empty((height, pitch), dtype=np.uint8)
+        self._check0(self.lib.rt_device_download(self.raw_context(0), ptr, raw.nbytes, raw.ctypes.data), "rt_device_download")
+        row = raw[:, : width * bytes_per_pixel]
+        if bytes_per_pixel == 16:
+            return np.ascontiguousarray(row).view(np.float32).reshape(height, width, 4)
+        return np.ascontiguousarray(row).reshape(height, width, 4)
+
+    def render(self, opts, camera, surf, pitch):
+        o = opts.contents if hasattr(opts, "contents") else opts
+        self._check(self.lib.rt_multi_render(self.m, C.byref(o), camera, surf, pitch, o.blockSize), "rt_multi_render")
+
+    def sync(self):
+        self._check(self.lib.rt_multi_sync(self.m), "rt_multi_sync")

@@ -70,15 +70,17 @@ def build_library(force=False, extra_device_flags=(), out=None, tag=""):
         objs.append(obj)
 
     compile_one(os.path.join(CSRC, "kernels", "rt_kernels.hip"), os.path.join(objdir, "rt_kernels.o"), [HIPCC, *DEVICE_FLAGS, *extra_device_flags])
-    # the BVH build kernels take no tuning flags; every variant links the default build's object
+    # the BVH build and tile kernels take no tuning flags; every variant links the default build's objects
     bvh_obj_dir = os.path.join(PKG, "build")
     os.makedirs(bvh_obj_dir, exist_ok=True)
     bvh_force, force = force, (force and not tag)
     compile_one(os.path.join(CSRC, "kernels", "rt_bvh_build.hip"), os.path.join(bvh_obj_dir, "rt_bvh_build.o"), [HIPCC, *DEVICE_FLAGS])
+    compile_one(os.path.join(CSRC, "kernels", "rt_tiles.hip"), os.path.join(bvh_obj_dir, "rt_tiles.o"), [HIPCC, *DEVICE_FLAGS])
     force = bvh_force
     # macro definitions of a tuning variant reach the host side too (the two share rt_device_format.h)
     host_cmd = [HIPCC, "-x", "c++", *HOST_FLAGS, "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", *[f for f in extra_device_flags if f.startswith("-D")]]
     compile_one(os.path.join(CSRC, "rt_capi.cpp"), os.path.join(objdir, "rt_capi.o"), host_cmd)
+    compile_one(os.path.join(CSRC, "rt_multi.cpp"), os.path.join(objdir, "rt_multi.o"), host_cmd)
     # only the entry points of include/rt_capi.h leave the library
     _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "rt_capi.map"), "-o", out, *objs])
     return out

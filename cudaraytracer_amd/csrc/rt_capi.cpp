@@ -1555,6 +1555,27 @@ int rt_render_noalloc(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, co
     return renderFrame(ctx, scene, opts, cam, devSurface, pitch, aux, true);
 }
 
+int rt_tiles_pack(rt_ctx* ctx, const void* devSurface, size_t pitch, int width, int height, const int32_t* devTiles, int tileCnt, void* devOut,
+                  int quantize) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (!devSurface || !devOut || width < 1 || height < 1 || tileCnt < 0 || (tileCnt > 0 && !devTiles) || pitch < (size_t)width * 16 || pitch % 16 != 0)
+        return fail(ctx, RT_ERR_INVALID, "bad tile pack arguments");
+    if (int r = bind(ctx)) return r;
+    RT_HIP(ctx, (hipError_t)rtk_pack_tiles(devSurface, pitch, width, height, devTiles, tileCnt, devOut, quantize ? 1 : 0, ctx->stream));
+    return RT_OK;
+}
+
+int rt_tiles_scatter(rt_ctx* ctx, const void* devIn, const int32_t* devTiles, int tileCnt, void* devSurface, size_t pitch, int width, int height,
+                     int quantized) {
+    if (!ctx) return RT_ERR_INVALID;
+    const size_t px = quantized ? 4 : 16;
+    if (!devSurface || !devIn || width < 1 || height < 1 || tileCnt < 0 || (tileCnt > 0 && !devTiles) || pitch < (size_t)width * px || pitch % px != 0)
+        return fail(ctx, RT_ERR_INVALID, "bad tile scatter arguments");
+    if (int r = bind(ctx)) return r;
+    RT_HIP(ctx, (hipError_t)rtk_scatter_tiles(devIn, devTiles, tileCnt, devSurface, pitch, width, height, quantized ? 1 : 0, ctx->stream));
+    return RT_OK;
+}
+
 int rt_timing_reset(rt_ctx* ctx) {
     if (!ctx) return RT_ERR_INVALID;
     ctx->launchesUsed = 0;

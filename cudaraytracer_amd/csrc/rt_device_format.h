@@ -276,6 +276,12 @@ int rtk_refit_tree(void* pairs, uint32_t pairBase, uint32_t pairCnt, int depth, 
 // to quads[quadBase + i] and the interior references inside become quadBase-relative.  Enqueued on `stream`.
 int rtk_build_quads(const void* pairs, uint32_t pairBase, uint32_t pairCnt, void* quads, uint32_t quadBase, void* stream);
 
+// Tile gather (kernels/rt_tiles.hip): the pixels of `tileCnt` 8x8 tiles (frame tile indices in device memory) out of a
+// float4 surface into a packed buffer (64 pixels per tile; float4, or 8-bit RGBA by the dump rule with `quantize`),
+// and from such a buffer into a surface (float4, or 8-bit RGBA with `quantized`).  Enqueued on `stream`; hipError_t.
+int rtk_pack_tiles(const void* surface, size_t pitch, int width, int height, const int32_t* tiles, int tileCnt, void* out, int quantize, void* stream);
+int rtk_scatter_tiles(const void* in, const int32_t* tiles, int tileCnt, void* surface, size_t pitch, int width, int height, int quantized, void* stream);
+
 // Device address and size of the CURRENT device's copy of the library's static scratch array (the workspace of
 // rt_render_noalloc).  Returns a hipError_t value.
 int rtk_scratch(void** devPtr, size_t* bytes);

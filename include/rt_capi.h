@@ -233,7 +233,7 @@ typedef struct rt_ctx rt_ctx;
 typedef struct rt_scene rt_scene;
 
 /* ---- context -------------------------------------------------------------
- * One context per GPU and per host thread.  Replaces the implicit CUDA
+ * One context per GPU and per host thread (rt_multi, at the end of this file, drives several from one thread).  Replaces the implicit CUDA
  * context + `__device__` globals of cudaTracer/Main.cu:11-13.  `device` is the
  * HIP device ordinal. */
 rt_ctx* rt_create(int device);
@@ -473,6 +473,55 @@ int rt_stream_wait_frame(rt_ctx* ctx, void* hipStream, int framesAgo);
 /* Tuning knob: upper bound on persistent trace wavefronts per CU (0 = as many as
  * the hardware keeps resident).  Results do not depend on it. */
 int rt_set_trace_waves(rt_ctx* ctx, int wavesPerCu);
+
+/* ---- tile gather ------------------------------------------------------------
+ * The two ends of a multi-GPU frame's gather, as device kernels on the context's stream.  rt_tiles_pack copies the
+ * pixels of `tileCnt` 8x8 tiles (`devTiles`: frame tile indices, row-major over the tile grid, in device memory) out
+ * of a float4 surface into `devOut`, 64 pixels per tile, tile after tile in list order (pixels of an edge tile that
+ * lie outside the frame are zero); rt_tiles_scatter writes such a buffer to the tiles' places in a surface.  With
+ * `quantize` the packed pixels are 8-bit RGBA by the rule of the reference's image dump, clamp((int)(v * 256), 0,
+ * 255) on all four channels (cudaTracer/PicDumper.h:43-55) - a quarter of the bytes to move - and the scatter's
+ * target is an 8-bit RGBA surface (4 bytes per pixel).  Order them behind a frame that runs on an internal stream
+ * (rt_set_frames_in_flight > 1) with rt_stream_wait_frame.  The reference has one GPU and no counterpart. */
+int rt_tiles_pack(rt_ctx* ctx, const void* devSurface, size_t pitch, int width, int height, const int32_t* devTiles, int tileCnt,
+                  void* devOut, int quantize);
+int rt_tiles_scatter(rt_ctx* ctx, const void* devIn, const int32_t* devTiles, int tileCnt, void* devSurface, size_t pitch, int width,
+                     int height, int quantized);
+
+/* ---- several GPUs from one host process -------------------------------------
+ * The reference's caller is one process that calls cudamain once per frame (cudaTracer/RayTracer.cpp:188-208,
+ * cudaTracer/main.cuh:7-12).  rt_multi keeps that shape for a node with several GPUs: one context per device, the
+ * scene flattened and uploaded once to devices[0] and copied from there to every peer (device-to-device, each peer
+ * over its own link), every device rendering its own list of 8x8 tiles of the SAME frame, and the tiles gathered
+ * into the caller's surface on devices[0] (packed on the peer, one peer copy, scattered on devices[0]).  No second
+ * process and no collective.  A device may be named more than once (several contexts on one GPU): the frame is the
+ * same, which is how a one-GPU machine exercises the path.
+ *   rt_multi_context(m, i)     the i-th device's context, for the per-context knobs (rt_set_upload_refit and
+ *                              rt_set_device_bvh on context 0 apply to rt_multi_scene_upload; do not change its
+ *                              stream, tile list or frames in flight)
+ *   rt_multi_scene_upload      replaces the current scene
+ *   rt_multi_balance           renders a counter frame and deals the tiles out so that every device gets the same
+ *                              number of tiles and (nearly) the same number of box + triangle tests; until it is
+ *                              called, and again after the frame size changes, tile t belongs to device t % ndev
+ *   rt_multi_set_quantize      on: `devSurface` of rt_multi_render is an 8-bit RGBA surface (4 bytes per pixel, dump
+ *                              rule as in rt_tiles_pack) and the tiles travel as bytes
+ *   rt_multi_render            cudamain for the node: enqueues the frame on all devices and the gather behind it;
+ *                              `devSurface` is memory of devices[0]
+ *   rt_multi_sync              waits for everything enqueued; reports what rt_sync reports
+ * Errors: rt_multi_last_error(m) (m == NULL: of the last failed rt_multi_create). */
+typedef struct rt_multi rt_multi;
+rt_multi* rt_multi_create(int ndev, const int* devices);
+void rt_multi_destroy(rt_multi* m);
+const char* rt_multi_last_error(const rt_multi* m);
+int rt_multi_device_count(const rt_multi* m);
+rt_ctx* rt_multi_context(rt_multi* m, int i);
+int rt_multi_scene_upload(rt_multi* m, const RtSceneDesc* desc);
+int rt_multi_scene_set_lights(rt_multi* m, const RtLight* lights, int lightCnt);
+int rt_multi_balance(rt_multi* m, const RtDeviceOpts* opts, const RtCamera* cam);
+int rt_multi_tile_counts(const rt_multi* m, int* counts); /* tiles per device of the current assignment */
+int rt_multi_set_quantize(rt_multi* m, int on);
+int rt_multi_render(rt_multi* m, const RtDeviceOpts* opts, const RtCamera* cam, void* devSurface, size_t pitch, int blockDim);
+int rt_multi_sync(rt_multi* m);
 
 /* cu_initCurand / cu_cleanCurand (cudaTracer/Main.cu:113-150) have no
  * counterpart: the jitter is a hash of (seed, pixel, sample, axis) and keeps

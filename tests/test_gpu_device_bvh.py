@@ -183,9 +183,9 @@ def test_ranges_of_coinciding_centroids_build_on_the_device(gpu_ctx, oracle, rtl
         tris.append(hs.tri(*[tuple(float(x) for x in v) for v in p]))
     lights = [((0, 4, 0), (1, 1, 1), 8.0), ((3, 0, 2), (1, 1, 1), 5.0)]
     w, h = 96, 64
-    # the oracle walks the host builder's tree, whose clumps are single leaves of 25
+    # the oracle walks the host builder's tree, in which a range that holds only triangles of one clump stays one leaf
     ordered, spec = bvh_of(rtlib, tris, 0, 10, 1)
-    assert max(n[3] for n in spec) == 25
+    assert max(n[3] for n in spec) > 10
     host_scene = hs.Scene(w, h, [hs.Mesh(ordered, nodes=spec)], lights=lights)
     ref_rgba, ref_keys = host_scene.render_oracle(oracle)
     # hand_scenes numbers a triangle's vertices by its position in the list: give both scenes the leaf-ordered list

@@ -1,0 +1,135 @@
+"""rt_multi_* : several devices from one host process.  On a one-GPU box the same device is named two or three times -
+every context then is its own "GPU" with its own scene copy, tile list, surface and stream, and the peer copies are
+device-to-device copies - and the gathered frame must be the single-context frame bit for bit."""
+import numpy as np
+import pytest
+
+import cudaraytracer_amd as rt
+from parity import to_8bit
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    return bool(((a == b) | (np.isnan(a) & np.isnan(b))).all())
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0], [0, 0, 0]])
+@pytest.mark.parametrize("name,w,h,size,lights,depth", [("mixed", 203, 117, 0, 3, 3), ("soup", 320, 200, 30000, 2, 0)])
+def test_gathered_frame_equals_the_single_context_frame(gpu_ctx, devices, name, w, h, size, lights, depth):
+    scene = rt.HostScene(name, w, h, size, lights, depth, tight_bvh=True)
+    want = gpu_ctx.render_frame(scene)[0]
+    with rt.MultiContext(devices) as m:
+        m.upload(scene)
+        surf, pitch = m.surface(w, h)
+        tiles = ((w + 7) // 8) * ((h + 7) // 8)
+        # interleaved tiles first, two frames in a row (the second reuses the receive buffers)
+        for _ in range(2):
+            m.render(scene.opts, scene.camera, surf, pitch)
+        m.sync()
+        assert sum(m.tile_counts()) == tiles and max(m.tile_counts()) - min(m.tile_counts()) <= 1
+        assert _same(m.download(surf, pitch, w, h), want)
+        # then lists of equal measured cost
+        m.balance(scene.opts, scene.camera)
+        assert sum(m.tile_counts()) == tiles and max(m.tile_counts()) - min(m.tile_counts()) <= 1
+        m.render(scene.opts, scene.camera, surf, pitch)
+        m.sync()
+        assert _same(m.download(surf, pitch, w, h), want)
+        # moving lights reach every device
+        scene.rotate_lights(0.5)
+        m.set_lights(scene.desc)
+        m.render(scene.opts, scene.camera, surf, pitch)
+        m.sync()
+        dscene = gpu_ctx.upload(scene)
+        moved = gpu_ctx.render_frame(scene, dscene)[0]
+        gpu_ctx.free_scene(dscene)
+        assert not _same(moved, want) and _same(m.download(surf, pitch, w, h), moved)
+        # 8-bit output: the dump rule on every channel
+        m.set_quantize(True)
+        surf8, pitch8 = m.surface(w, h, 4)
+        m.render(scene.opts, scene.camera, surf8, pitch8)
+        m.sync()
+        assert np.array_equal(m.download(surf8, pitch8, w, h, 4).astype(np.int32), to_8bit(moved))
+
+
+def test_another_frame_size_and_a_new_scene(gpu_ctx):
+    a = rt.HostScene("cubes", 160, 120, 6, 2, 2)
+    b = rt.HostScene("mixed", 96, 64, 0, 2, 2)
+    with rt.MultiContext([0, 0]) as m:
+        for scene in (a, b, a):
+            w, h = scene.width, scene.height
+            m.upload(scene)
+            surf, pitch = m.surface(w, h)
+            m.render(scene.opts, scene.camera, surf, pitch)
+            m.sync()
+            assert _same(m.download(surf, pitch, w, h), gpu_ctx.render_frame(scene)[0])
+
+
+def test_upload_refit_applies_to_the_shared_blob(gpu_ctx):
+    """A knob set on context 0 shapes the blob every device gets: reference boxes in, refitted boxes on all devices."""
+    w, h = 160, 96
+    scene = rt.HostScene("soup", w, h, 30000, 1, 0, tight_bvh=False)
+    want = gpu_ctx.render_frame(scene)[0]
+    with rt.MultiContext([0, 0]) as m:
+        assert m.lib.rt_set_upload_refit(m.raw_context(0), 1) == 0
+        m.upload(scene)
+        surf, pitch = m.surface(w, h)
+        m.render(scene.opts, scene.camera, surf, pitch)
+        m.sync()
+        assert _same(m.download(surf, pitch, w, h), want)
+
+
+def test_bad_arguments():
+    lib = rt.load()
+    assert not lib.rt_multi_create(0, None)
+    assert b"devices" in lib.rt_multi_last_error(None)
+    import ctypes as C
+
+    assert not lib.rt_multi_create(1, (C.c_int * 1)(9999))
+    with rt.MultiContext([0]) as m:
+        scene = rt.HostScene("cubes", 64, 48, 2, 1, 0)
+        surf, pitch = m.surface(64, 48)
+        with pytest.raises(rt.RtError, match="no scene"):
+            m.render(scene.opts, scene.camera, surf, pitch)
+        m.upload(scene)
+        with pytest.raises(rt.RtError, match="pitch"):
+            m.render(scene.opts, scene.camera, surf, 64 * 16 - 16)
+
+
+def test_tile_pack_and_scatter_round_trip(gpu_ctx):
+    """rt_tiles_pack / rt_tiles_scatter on a ragged frame: the listed tiles arrive where they came from, the others stay."""
+    w, h = 203, 117
+    scene = rt.HostScene("mixed", w, h, 0, 2, 1)
+    frame = gpu_ctx.render_frame(scene)[0]
+    tx, ty = (w + 7) // 8, (h + 7) // 8
+    tiles = np.arange(1, tx * ty, 3, dtype=np.int32)[::-1].copy()
+    dscene = gpu_ctx.upload(scene)
+    src, pitch = gpu_ctx.surface(w, h)
+    dst, _ = gpu_ctx.surface(w, h)
+    dev_tiles = gpu_ctx.alloc(tiles.nbytes)
+    packed = gpu_ctx.alloc(tiles.size * 64 * 16)
+    lib, ctx = gpu_ctx.lib, gpu_ctx.ctx
+    try:
+        import torch
+
+        t = torch.from_numpy(tiles).cuda()
+        torch.cuda.synchronize()
+        gpu_ctx.render(dscene, scene.opts, scene.camera, src, pitch)
+        gpu_ctx.zero(dst, pitch * h)
+        assert lib.rt_tiles_pack(ctx, src, pitch, w, h, t.data_ptr(), tiles.size, packed, 0) == 0
+        assert lib.rt_tiles_scatter(ctx, packed, t.data_ptr(), tiles.size, dst, pitch, w, h, 0) == 0
+        gpu_ctx.sync()
+        got = gpu_ctx.download_surface(dst, pitch, w, h)
+        mask = np.zeros((h, w), dtype=bool)
+        for tile in tiles:
+            mask[(tile // tx) * 8:(tile // tx) * 8 + 8, (tile % tx) * 8:(tile % tx) * 8 + 8] = True
+        assert _same(got[mask], frame[mask]) and (got[~mask] == 0).all()
+        flat = gpu_ctx.download(packed, (tiles.size, 8, 8, 4), np.float32)
+        k = 5
+        ty0, tx0 = (tiles[k] // tx) * 8, (tiles[k] % tx) * 8
+        assert _same(flat[k][: min(8, h - ty0), : min(8, w - tx0)], frame[ty0:ty0 + 8, tx0:tx0 + 8])
+        assert dev_tiles
+    finally:
+        for p in (src, dst, dev_tiles, packed):
+            gpu_ctx.free(p)
+        gpu_ctx.free_scene(dscene)
