@@ -340,12 +340,15 @@ def main():
     surfaces = [torch.zeros((h, w, 4), dtype=torch.float32, device=dev) for _ in range(nf)]
     surface = surfaces[0]
     pitch = w * 16
-    gatherer = mg.TileGather(w, h, rank, world, comm_dev) if multi else None
+    # RT_BENCH_TORCH_GATHER=1 (development): pack / assemble tiles with torch index arithmetic instead of the library's kernels
+    use_kernels = os.environ.get("RT_BENCH_TORCH_GATHER") != "1"
+    gatherer = mg.TileGather(w, h, rank, world, comm_dev, ctx=ctx if use_kernels else None) if multi else None
     if multi:
         # frame i renders into surface i % F; the oldest frame in flight is gathered to rank 0 (where it then sits as
         # 8x8-pixel tiles, rank by rank; TileGather.assembled() lays it out as rows) while the newer ones keep rendering
         pipe = mg.FramePipeline(surfaces, lambda s, i: ctx.render(dscene, opts, camera_ref, s.data_ptr(), pitch, None, None, *shard),
-                                lambda ago: ctx.stream_wait_frame(stream.cuda_stream, ago), gatherer, (lambda s: s.to(comm_dev)))
+                                lambda ago: ctx.stream_wait_frame(stream.cuda_stream, ago), gatherer,
+                                None if use_kernels else (lambda s: s.to(comm_dev)))
     else:
         pipe = mg_single(surfaces, lambda s: ctx.render(dscene, opts, camera_ref, s.data_ptr(), pitch))
     step, drain = pipe.step, pipe.drain
@@ -547,6 +550,8 @@ def main():
                                          f"8x8 tiles, per-GPU lists of equal measured cost (box + triangle tests of a counter frame), gathered to GPU0 each frame"
                                          if balance else f"8x8 tiles, tile t on GPU t % {world}, gathered to GPU0 each frame"),
                        "tile_balance": balance,
+                       "gather": None if not multi else ("tiles packed / assembled by the library's kernels (rt_tiles_pack / rt_tiles_scatter)" if use_kernels
+                                                         else "tiles packed / assembled by torch index arithmetic"),
                        "frames_in_flight": nf,
                        "frame_latency_ms_with_frames_in_flight": in_flight_stage[0],
                        "in_order": {"ms_per_frame": frame_ms, "wall_ms_per_frame": alone_wall, "Mrays_per_s": rays / alone_wall / 1e3,

@@ -282,6 +282,14 @@ class Context:
         o = opts.contents if hasattr(opts, "contents") else opts
         self._check(self.lib.rt_render_noalloc(self.ctx, scene, C.byref(o), camera, surf, pitch, o.blockSize, C.byref(aux)), "rt_render_noalloc")
 
+    def tiles_pack(self, surf, pitch, width, height, dev_tiles, count, dev_out, quantize=False):
+        """rt_tiles_pack: the pixels of `count` 8x8 tiles (int32 tile indices in device memory) out of a float4 surface."""
+        self._check(self.lib.rt_tiles_pack(self.ctx, surf, pitch, width, height, dev_tiles, count, dev_out, 1 if quantize else 0), "rt_tiles_pack")
+
+    def tiles_scatter(self, dev_in, dev_tiles, count, surf, pitch, width, height, quantized=False):
+        """rt_tiles_scatter: packed tiles to their places in a surface (float4, or 8-bit RGBA when quantized)."""
+        self._check(self.lib.rt_tiles_scatter(self.ctx, dev_in, dev_tiles, count, surf, pitch, width, height, 1 if quantized else 0), "rt_tiles_scatter")
+
     def sync(self):
         self._check(self.lib.rt_sync(self.ctx), "rt_sync")
 

@@ -138,10 +138,19 @@ class TileGather:
     quarter of the bytes over xGMI for a consumer that only wants the picture.
 
     Rank 0 receives every peer's tiles straight into one [world, tiles per rank, 8, 8, c] buffer (one irecv per peer,
-    all in flight together) and brings them into tile order with a single gather."""
+    all in flight together) and brings them into tile order with a single gather.
 
-    def __init__(self, width, height, rank, world, device, channels=4, dtype=torch.float32, assignment=None, quantize=False):
+    `ctx` (an api.Context of this rank's GPU): float4 surfaces in device memory are then packed and, on rank 0,
+    assembled by the library's own kernels (rt_tiles_pack / rt_tiles_scatter, enqueued on the context's stream, which
+    must be torch's current stream) instead of torch index arithmetic: one launch per end and rank, nothing
+    allocated per frame.  `device` stays the device the transfers run on (the GPU for RCCL; "cpu" for a rehearsal over
+    gloo, where the packed tiles cross to the host and back)."""
+
+    def __init__(self, width, height, rank, world, device, channels=4, dtype=torch.float32, assignment=None, quantize=False, ctx=None):
         self.w, self.h, self.rank, self.world, self.device = width, height, rank, world, device
+        self.ctx = ctx
+        if ctx is not None and (channels != 4 or dtype != torch.float32):
+            raise ValueError("the library's tile kernels move float4 pixels")
         self.tx, self.ty = tile_grid(width, height)
         self.c = channels
         self.n = self.tx * self.ty
@@ -179,9 +188,22 @@ class TileGather:
             for r, l in enumerate(lists):
                 where[l] = r * self.per + torch.arange(l.numel())
             self.where = where.to(device)
+        if self.ctx is not None:
+            gpu = torch.device("cuda", torch.cuda.current_device())
+            self.k_tiles = lists[self.rank].to(torch.int32).to(gpu)
+            self.k_packed = torch.empty((max(self.counts[self.rank], 1), TILE, TILE, self.c), dtype=self.dtype, device=gpu)
+            if self.rank == 0:
+                self.k_lists = [l.to(torch.int32).to(gpu) for l in lists]
+                self.k_frame = torch.zeros((self.h, self.w, self.c), dtype=self.dtype, device=gpu)
 
     def tiles(self, surface):
-        """[h, w, c] surface -> [tiles, 8, 8, c] of this rank's tiles (a copy; 8-bit if the gather quantizes)."""
+        """[h, w, c] surface -> [tiles, 8, 8, c] of this rank's tiles (8-bit if the gather quantizes).  With the
+        library's kernel the result is this object's own buffer, overwritten by the next call."""
+        if self.ctx is not None and surface.is_cuda:
+            n = self.counts[self.rank]
+            self.ctx.tiles_pack(surface.data_ptr(), surface.stride(0) * surface.element_size(), self.w, self.h, self.k_tiles.data_ptr(), n,
+                                self.k_packed.data_ptr(), self.quantize)
+            return self.k_packed[:n]
         t = surface.view(self.h * self.w, self.c).index_select(0, self.pixels).view(-1, TILE, TILE, self.c)
         return quantize8(t) if self.quantize else t
 
@@ -189,6 +211,8 @@ class TileGather:
         """Every rank passes its own surface (only its tiles are read).  Rank 0 returns the assembled [h, w, c] frame,
         or, with assemble=False, leaves the tiles as they arrived (rank by rank) for a later assembled() call."""
         mine = self.tiles(surface)
+        if mine.device != torch.device(self.device):
+            mine = mine.to(self.device)  # packed on the GPU, sent from the host: a rehearsal over gloo
         # Both sides use the batched point-to-point call: on RCCL it puts rank 0's N-1 receives into ONE group, so
         # they run concurrently over the peers' separate xGMI links, and it keeps sender and receiver on the same
         # communicator.
@@ -205,7 +229,16 @@ class TileGather:
         return self.assembled() if assemble else None
 
     def assembled(self):
-        """Rank 0: the latest gathered frame as [h, w, c] (a copy): tiles into tile order, rows laid out, edge cropped."""
+        """Rank 0: the latest gathered frame as [h, w, c]: tiles into tile order, rows laid out, edge cropped.  (With the
+        library's kernels: one scatter launch per rank into this object's frame tensor, which the next call rewrites.)"""
+        if self.ctx is not None:
+            buf = self.buf if self.buf.is_cuda else self.buf.to(self.k_frame.device)
+            pitch = self.w * self.c * self.k_frame.element_size()
+            for r in range(self.world):
+                if self.counts[r]:
+                    self.ctx.tiles_scatter(buf[r].data_ptr(), self.k_lists[r].data_ptr(), self.counts[r], self.k_frame.data_ptr(), pitch, self.w, self.h,
+                                           self.quantize)
+            return self.k_frame
         flat = self.frame.view(self.n, TILE, TILE, self.c)
         torch.index_select(self.buf.view(self.world * self.per, TILE, TILE, self.c), 0, self.where, out=flat)
         full = self.frame.permute(0, 2, 1, 3, 4).reshape(self.ty * TILE, self.tx * TILE, self.c)

@@ -133,3 +133,38 @@ def test_tile_pack_and_scatter_round_trip(gpu_ctx):
         for p in (src, dst, dev_tiles, packed):
             gpu_ctx.free(p)
         gpu_ctx.free_scene(dscene)
+
+
+@pytest.mark.parametrize("quantize", [False, True])
+def test_tile_gather_with_the_librarys_kernels(gpu_ctx, quantize):
+    """multi.TileGather packing and assembling with rt_tiles_pack / rt_tiles_scatter (a world of one, no transfer) gives
+    the frame the torch index arithmetic gives - and both give back the surface."""
+    import torch
+
+    from cudaraytracer_amd import multi as mg
+
+    w, h = 203, 117
+    scene = rt.HostScene("mixed", w, h, 0, 2, 1)
+    dscene = gpu_ctx.upload(scene)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    try:
+        with torch.cuda.stream(stream):
+            gpu_ctx.set_stream(stream.cuda_stream)
+            surface = torch.zeros((h, w, 4), dtype=torch.float32, device=dev)
+            gpu_ctx.render(dscene, scene.opts, scene.camera, surface.data_ptr(), w * 16)
+            tx, ty = mg.tile_grid(w, h)
+            order = torch.randperm(tx * ty, generator=torch.Generator().manual_seed(3))
+            fast = mg.TileGather(w, h, 0, 1, dev, assignment=[order], quantize=quantize, ctx=gpu_ctx)
+            slow = mg.TileGather(w, h, 0, 1, dev, assignment=[order], quantize=quantize)
+            fast.gather(surface, assemble=False)
+            a = fast.assembled().clone()
+            b = slow.gather(surface)
+            gpu_ctx.sync()
+            stream.synchronize()
+        want = mg.quantize8(surface) if quantize else surface
+        assert torch.equal(a, b) or bool(((a == b) | (a.isnan() & b.isnan())).all())
+        assert bool(((a == want) | (a.float().isnan() & want.float().isnan())).all())
+    finally:
+        gpu_ctx.set_stream(None)
+        gpu_ctx.free_scene(dscene)
