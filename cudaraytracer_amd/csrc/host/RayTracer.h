@@ -174,8 +174,35 @@ class RayTracer {
         check(rt_surface_create(ctx, options.device.width, options.device.height, &surface, &pitch), "rt_surface_create");
     }
 
+    // The same for a node with several GPUs (rt_multi_*): the scene goes to devices[0] and from there to the peers, every
+    // device renders its share of each frame's tiles, and the frame arrives in a surface on devices[0].
+    // `balanceTiles`: deal the tiles out by the measured cost of a first frame instead of tile t -> device t % n.
+    void upload(rt_multi* node, bool balanceTiles = true) {
+        release();
+        multi = node;
+        ctx = rt_multi_context(node, 0);
+        std::vector<RtShape> shapeStore;
+        std::vector<RtMesh> meshStore;
+        const RtSceneDesc desc = currentScene().describe(shapeStore, meshStore);
+        check(rt_set_upload_refit(ctx, refitAtUpload ? 1 : 0), "rt_set_upload_refit");
+        checkMulti(rt_multi_scene_upload(multi, &desc), "rt_multi_scene_upload");
+        check(rt_surface_create(ctx, options.device.width, options.device.height, &surface, &pitch), "rt_surface_create");
+        if (balanceTiles) {
+            const RtCamera cam = currentScene().cameraDesc();
+            checkMulti(rt_multi_balance(multi, options.device.abi(), &cam), "rt_multi_balance");
+        }
+    }
+
     // One frame: advance the lights, re-upload them, render (RayTracer::update).
     void update(float dt) {
+        if (multi) {
+            updateLights(dt);
+            checkMulti(rt_multi_scene_set_lights(multi, reinterpret_cast<const RtLight*>(lights.data()), (int)lights.size()), "rt_multi_scene_set_lights");
+            const RtCamera cam = currentScene().cameraDesc();
+            checkMulti(rt_multi_render(multi, options.device.abi(), &cam, surface, pitch, options.device.blockSize), "rt_multi_render");
+            checkMulti(rt_multi_sync(multi), "rt_multi_sync");
+            return;
+        }
         if (!devScene) throw std::logic_error("RayTracer: upload() first");
         updateLights(dt);
         check(rt_scene_set_lights(devScene, reinterpret_cast<const RtLight*>(lights.data()), (int)lights.size()),
@@ -197,13 +224,19 @@ class RayTracer {
     }
 
     void release() {
+        if (multi) (void)rt_multi_sync(multi);  // (the node object keeps the scene copies; its owner destroys it)
         if (devScene) rt_scene_free(devScene);
         if (surface) rt_surface_free(ctx, surface);
         devScene = nullptr;
         surface = nullptr;
+        multi = nullptr;
     }
 
    private:
+    rt_multi* multi = nullptr;
+    void checkMulti(int rc, const char* what) {
+        if (rc != RT_OK) throw std::runtime_error(std::string(what) + ": " + rt_multi_last_error(multi));
+    }
     rt_ctx* ctx = nullptr;
     rt_scene* devScene = nullptr;
     void* surface = nullptr;

@@ -168,3 +168,27 @@ def test_tile_gather_with_the_librarys_kernels(gpu_ctx, quantize):
     finally:
         gpu_ctx.set_stream(None)
         gpu_ctx.free_scene(dscene)
+
+
+def test_cpp_driver_on_two_contexts(tmp_path):
+    """examples/headless_tracer --gpus 0,0: the C++ RayTracer class over rt_multi_*; the dumped picture is the one the
+    single-context run dumps."""
+    import json
+    import os
+    import subprocess
+
+    from PIL import Image
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "headless_tracer")
+    if not os.path.exists(exe):
+        pytest.skip("examples/headless_tracer not built")
+    doc = tmp_path / "exp.json"
+    doc.write_text(json.dumps({"name": "node", "phases": [{"name": "small", "options": {"width": 160, "height": 120, "lightCnt": 3, "maxDepth": 2}}]}))
+    pics = []
+    for gpus, name in (("1", "one.png"), ("0,0", "two.png"), ("0,0,0", "three.png")):
+        r = subprocess.run([exe, str(doc), "0", "--frames", "2", "--gpus", gpus, "--out", str(tmp_path / name)], capture_output=True, text=True, cwd=tmp_path)
+        assert r.returncode == 0, r.stderr
+        pics.append(np.asarray(Image.open(tmp_path / name).convert("RGBA")))
+    assert f"on {2} GPU context(s)" in r.stdout or "on 3 GPU context(s)" in r.stdout
+    assert np.array_equal(pics[0], pics[1]) and np.array_equal(pics[0], pics[2])
+    assert pics[0][..., :3].std() > 10  # a picture, not a blank frame
