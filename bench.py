@@ -40,7 +40,7 @@ FP32_VECTOR_PEAK_TFLOPS = 256 * 4 * 32 * 2 * 2.4e9 / 1e12  # 256 CUs x 4 SIMDs x
 # algorithmic work per test (the survey's per-unit figures)
 NODE_FLOPS, TRI_FLOPS, SPHERE_FLOPS, MESH_ENTRY_FLOPS = 24, 60, 30, 31
 HIT_RECORD_BYTES = 20  # float4 {t, u, v, shape} + int triangle, written per traced path node
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 def parse():

@@ -25,5 +25,8 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
 pass ta TA_TA_BUSY_sum TA_BUSY_avr TCP_GATE_EN1_sum TCP_PENDING_STALL_CYCLES_sum
-python3 profiles/summarize_pmc.py "$OUT" > "$OUT/summary.txt" 2>&1; tail -60 "$OUT/summary.txt"
+# one run writes the summary and the table bench.py reads (copy both, and trace/*_kernel_stats.csv, into profiles/<round>/)
+WORKLOAD=${WORKLOAD:-soup-1000000-1920x1080-l1-d0}
+python3 profiles/summarize_pmc.py "$OUT" --traffic-json "$OUT/traffic.json" --workload "$WORKLOAD" --summary-out "$OUT/pmc_summary.txt" > /dev/null 2>&1
+tail -60 "$OUT/pmc_summary.txt"
 echo done

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Prints per-kernel means of a profiles/run_pmc.sh / run_profile.sh output directory.
 
-  summarize_pmc.py <dir> [--traffic-json profiles/traffic.json --workload KEY]
+  summarize_pmc.py <dir> [--traffic-json profiles/traffic.json --workload KEY] [--summary-out FILE]
 
+--summary-out also writes what is printed to FILE, so that ONE run of this script produces both the committed
+summary and the table bench.py reads (tests/test_profiles.py compares the two).
 With --traffic-json the HBM bytes per launch (and the vector instructions per launch, SQ_INSTS_VALU) of every kernel
 that has FETCH_SIZE and WRITE_SIZE samples are merged into that file:
   hbm = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024
@@ -22,8 +24,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument("out")
 ap.add_argument("--traffic-json")
 ap.add_argument("--workload", default="default")
+ap.add_argument("--summary-out")
 args = ap.parse_args()
 out = args.out
+lines = []
+_print = print
+
+
+def print(*a):  # noqa: A001 - everything printed is also collected for --summary-out
+    _print(*a)
+    lines.append(" ".join(str(x) for x in a))
+
 
 
 def short(name):
@@ -55,10 +66,15 @@ for k, d in sorted(agg.items()):
         if "SQ_INSTS_VALU" in d:  # wavefront-wide vector instructions per launch (4 SIMD cycles each)
             traffic[k]["valu_insts_per_launch"] = sum(d["SQ_INSTS_VALU"]) / len(d["SQ_INSTS_VALU"])
         print(f"   => HBM bytes per launch: 2 x {fetch/1e6:.1f} MB + {write/1e6:.1f} MB = {(2*fetch+write)/1e6:.1f} MB")
+        # the same figures, unrounded, as they go into the traffic table
+        print("   => table: " + json.dumps(traffic[k], sort_keys=True))
 if args.traffic_json and traffic:
     table = {}
     if os.path.exists(args.traffic_json):
         table = json.load(open(args.traffic_json))
     table[args.workload] = traffic
     json.dump(table, open(args.traffic_json, "w"), indent=1, sort_keys=True)
-    print("wrote", args.traffic_json)
+    print("wrote", args.traffic_json, "workload", args.workload)
+if args.summary_out:
+    with open(args.summary_out, "w") as f:
+        f.write("\n".join(lines) + "\n")
