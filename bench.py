@@ -186,20 +186,24 @@ def time_frames(ctx, render, frames, in_flight, surfaces):
 
 def other_workload(ctx, torch, dev, label, scene_args, scene_kwargs, nf):
     """In-order and in-flight figures of another workload of the scope table, on the same kernels.
-    scene_kwargs["upload_refit"]: upload with rt_set_upload_refit on (boxes recomputed on the device)."""
+    scene_kwargs["upload_refit"]: upload with rt_set_upload_refit on (boxes recomputed on the device);
+    scene_kwargs["upload_rebuild"]: with rt_set_upload_rebuild on (mesh BVHs built again on the device)."""
     scene_kwargs = dict(scene_kwargs)
     refit = scene_kwargs.pop("upload_refit", False)
+    rebuild = scene_kwargs.pop("upload_rebuild", False)
     t0 = time.perf_counter()
     scene = rt.HostScene(*scene_args, **scene_kwargs)
     build_s = time.perf_counter() - t0
     w, h = scene.width, scene.height
     ctx.set_upload_refit(refit)
+    ctx.set_upload_rebuild(rebuild)
     t0 = time.perf_counter()
     try:
         dscene = ctx.upload(scene)
         ctx.sync()
     finally:
         ctx.set_upload_refit(False)
+        ctx.set_upload_rebuild(False)
     upload_s = time.perf_counter() - t0
     surfaces = [torch.zeros((h, w, 4), dtype=torch.float32, device=dev) for _ in range(nf)]
     pitch = w * 16
@@ -484,6 +488,9 @@ def main():
              "and ties, true bounds; its cuts were made on FLT_MIN-clamped centroid bounds (cudaTracer/BVH.h:122-128), so it stays behind a tree "
              "built on true bounds",
              ("soup", w, h, args.size, args.lights, args.max_depth), {"tight_bvh": False, "upload_refit": True}),
+            ("cfg 2 handed over with the reference's own BVH, mesh BVHs built again on the device at upload (rt_set_upload_rebuild): the "
+             "reference's median cut on true bounds, same image; what a host that passes the reference's arrays gets with one switch",
+             ("soup", w, h, args.size, args.lights, args.max_depth), {"tight_bvh": False, "upload_rebuild": True}),
             ("cfg 1: 16x16 grid of cube meshes (one mesh BVH each) under a scene BVH, 640x480, 4 lights, maxDepth 5",
              ("cubes", 640, 480, 16, 4, 5), {"tight_bvh": True}),
             ("cfg 3: OBJ barrel (488 triangles, three 1024x1024 maps) in three instances, one a mirror, textured plane, mirror and "

@@ -120,6 +120,7 @@ C_ABI = {
     "rt_set_sample_seed": (C.c_int, [C.c_void_p, C.c_uint32]),
     "rt_set_device_bvh": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rt_set_upload_refit": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_set_upload_rebuild": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_bvh_refit": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "rt_scene_bvh_refit": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "rt_render_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(RtDeviceOpts), C.POINTER(RtCamera), C.c_void_p, C.c_size_t,

@@ -331,6 +331,10 @@ class Context:
         """Recompute the boxes of the trees a scene arrives with at upload (same topology, true bounds)."""
         self._check(self.lib.rt_set_upload_refit(self.ctx, 1 if on else 0), "rt_set_upload_refit")
 
+    def set_upload_rebuild(self, on=True):
+        """Build every mesh BVH on the device at upload, whether or not the mesh comes with nodes (rt_set_device_bvh's rule)."""
+        self._check(self.lib.rt_set_upload_rebuild(self.ctx, 1 if on else 0), "rt_set_upload_rebuild")
+
     def set_sample_seed(self, seed):
         self._check(self.lib.rt_set_sample_seed(self.ctx, seed), "rt_set_sample_seed")
 

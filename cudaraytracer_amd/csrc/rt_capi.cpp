@@ -61,7 +61,10 @@ constexpr int kGuardByte = 0xA5;
 struct BuildParams {
     int threshold = 10;
     int tightBounds = 1;
+    bool rebuildAll = false;  // rt_set_upload_rebuild: also meshes that arrive WITH nodes get their BVH on the device
 };
+// true if this mesh's BVH is built on the device at upload (its node array, if it has one, is not looked at)
+inline bool builtOnDevice(const RtMesh& m, const BuildParams* build) { return (m.nodeCnt == 0 && !m.nodes) || (build && build->rebuildAll); }
 
 }  // namespace
 
@@ -442,7 +445,7 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
         DevMesh& dm = meshes[mi];
         std::memset(&dm, 0, sizeof dm);
         if (m.triangleCnt < 1 || !m.triangles || m.vertexCnt < 1 || !m.vertices) return bad("mesh with missing triangles or vertices");
-        const bool onDevice = m.nodeCnt == 0 && !m.nodes;
+        const bool onDevice = builtOnDevice(m, builds ? build : nullptr);
         if (onDevice && !(build && builds)) return bad("mesh without BVH nodes: only rt_scene_upload can build them (on the device)");
         if (!onDevice && (m.nodeCnt < 1 || !m.nodes)) return bad("mesh with an inconsistent node array");
         for (int t = 0; t < m.triangleCnt; ++t)
@@ -548,7 +551,7 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
         std::memcpy(base + dm.offNodes, meshPairs[mi].data(), meshPairs[mi].size() * sizeof(RtLinearNode));
         std::memcpy(base + dm.offVertices, m.vertices, (size_t)m.vertexCnt * sizeof(RtVertex));
         TriRecord* rec = reinterpret_cast<TriRecord*>(base + dm.offTriRecords);
-        const bool onDevice = m.nodeCnt == 0 && !m.nodes;  // the device build writes this mesh's records
+        const bool onDevice = builtOnDevice(m, builds ? build : nullptr);  // the device build writes this mesh's records
         for (int t = 0; !onDevice && t < m.triangleCnt; ++t) {
             const float* p0 = m.vertices[m.triangles[t].i[0]].position;
             const float* p1 = m.vertices[m.triangles[t].i[1]].position;
@@ -997,7 +1000,8 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
     // with rt_set_upload_refit the blob is packed as it came and its boxes are recomputed on the device, below
-    int r = packScene(desc, host, &err, &ctx->bvhBuild, &builds, false, /*boxesWillBeRefit=*/ctx->uploadRefit);
+    const bool refitHere = ctx->uploadRefit || ctx->bvhBuild.rebuildAll;  // (a rebuild gives the scene BVH true boxes too)
+    int r = packScene(desc, host, &err, &ctx->bvhBuild, &builds, false, /*boxesWillBeRefit=*/refitHere);
     if (verbose) std::fprintf(stderr, "rt_scene_upload: packed %zu bytes in %.3f s\n", host.size(), now() - t0);
     if (r != RT_OK) {
         fail(ctx, r, "%s", err.c_str());
@@ -1041,7 +1045,7 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
     sc->ownsBlob = true;
     sc->bytes = host.size();
     std::memcpy(&sc->header, host.data(), sizeof(BlobHeader));
-    if (ctx->uploadRefit) {
+    if (refitHere) {
         t0 = now();
         const int rr = refitOnDevice(ctx, sc, host.data(), builds, desc);
         if (verbose) std::fprintf(stderr, "rt_scene_upload: bounds refit on the device in %.3f s\n", now() - t0);
@@ -1100,6 +1104,12 @@ int rt_set_device_bvh(rt_ctx* ctx, int threshold, int tightBounds) {
 int rt_set_upload_refit(rt_ctx* ctx, int on) {
     if (!ctx) return RT_ERR_INVALID;
     ctx->uploadRefit = on != 0;
+    return RT_OK;
+}
+
+int rt_set_upload_rebuild(rt_ctx* ctx, int on) {
+    if (!ctx) return RT_ERR_INVALID;
+    ctx->bvhBuild.rebuildAll = on != 0;
     return RT_OK;
 }
 

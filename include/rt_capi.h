@@ -367,6 +367,15 @@ int rt_set_device_bvh(rt_ctx* ctx, int threshold, int tightBounds);
  * for a mesh BVH (`triangles` in leaf order, as in RtMesh) and for the scene BVH (`shapes` in leaf order, as in
  * RtSceneDesc).  Their errors: rt_last_error(NULL). */
 int rt_set_upload_refit(rt_ctx* ctx, int on);
+/* Rebuild at upload: with `on` != 0, rt_scene_upload builds the BVH of EVERY mesh on the device, as rt_set_device_bvh
+ * describes, whether or not the mesh arrives with nodes (the node array is not looked at; the triangles may be in any
+ * order), and gives the scene BVH true boxes as rt_set_upload_refit does.  For a host that hands over the reference's
+ * own arrays (cudaTracer/CudaMesh.h:58-63): its trees were cut on FLT_MIN-clamped centroid bounds
+ * (cudaTracer/BVH.h:122-128 over cudaTracer/BoundingBox.cuh:25-27), which picks the wrong split axis wherever
+ * coordinates are negative, so even with refitted boxes a ray makes several times the tests it makes in a tree cut on
+ * true bounds.  Same hits as with the caller's trees, except equal-distance ties (the order of the tests is the new
+ * tree's).  1 M triangles: 15 ms.  rt_scene_pack (host only) ignores the switch.  Default: off. */
+int rt_set_upload_rebuild(rt_ctx* ctx, int on);
 int rt_bvh_refit(RtLinearNode* nodes, int nodeCnt, const RtVertex* vertices, int vertexCnt, const RtTriangle* triangles, int triangleCnt);
 int rt_scene_bvh_refit(RtLinearNode* nodes, int nodeCnt, const RtShape* shapes, int shapeCnt);
 
