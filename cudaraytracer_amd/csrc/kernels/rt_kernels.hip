@@ -705,11 +705,12 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     wNodeSteps++;
                     wNodeLanes += pop64(nodeMask);
                 }
+                RT_PROBE_QUAD_VOTE();
                 if (kQuad && (int)cur >= 0) {
                     // One 128-byte fetch: the child pairs of both children of the node (halves A and B).  The children's
                     // own boxes are not tested: a grandchild's box lies inside its parent's, so a ray that passes the
                     // grandchild's test would have passed the parent's, with a smaller entry distance.
-                    const float4* p = P.quads + ((size_t)RT_REF_PAIR_UNITS(cur) << 3);
+                    const float4* p = P.quads + ((size_t)RT_PROBE_QUAD_UNITS(cur) << 3);
                     const float4 A0 = p[0], A1 = p[1], A2 = p[2], A3 = p[3], B0 = p[4], B1 = p[5], B2 = p[6], B3 = p[7];
                     const auto B = [](bool c) { return __builtin_amdgcn_ballot_w64(c); };
                     float ta0, fa0, ta1, fa1, tb0, fb0, tb1, fb1;
@@ -735,7 +736,8 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                     const unsigned long long hBf = (mNB & hB1) | (~mNB & hB0), hBs = (mNB & hB0) | (~mNB & hB1);
                     const unsigned long long h0 = (mNP & hBf) | (~mNP & hAf), h1 = (mNP & hBs) | (~mNP & hAs);
                     const unsigned long long h2 = (mNP & hAf) | (~mNP & hBf), h3 = (mNP & hAs) | (~mNP & hBs);
-                    const unsigned r0 = negP ? rBf : rAf, r1 = negP ? rBs : rAs, r2 = negP ? rAf : rBf, r3 = negP ? rAs : rBs;
+                    unsigned r0 = negP ? rBf : rAf, r1 = negP ? rBs : rAs, r2 = negP ? rAf : rBf, r3 = negP ? rAs : rBs;
+                    RT_PROBE_QUAD_STEP();
                     const float t1 = negP ? tBs : tAs, t2 = negP ? tAf : tBf, t3 = negP ? tAs : tBs;
                     // the first of the four that is hit is entered, the later ones wait on the stack, the next one on top
                     if (__builtin_amdgcn_inverse_ballot_w64(h3 & (h0 | h1 | h2))) push(r3, __float_as_uint(t3));
@@ -967,6 +969,7 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
         STAMP(10);  // results published
     }
 
+    RT_PROBE_QUAD_FLUSH();
     if (COUNT && P.counters) {
         RT_PROBE_FLUSH();
         unsigned vals[6] = {cNode, cTri, cSphere, cMesh, cRays, cPrimary};
@@ -1334,6 +1337,7 @@ __global__ void __launch_bounds__(256) resolveKernel(const FrameParams P, const 
 
 // cudaTracer/Main.cu:66-98: sample sum (from 0), average, gamma, store.
 __global__ void __launch_bounds__(256) finalizeKernel(const FrameParams P) {
+    RT_PROBE_QUAD_REPORT();
     const int S = P.opts.samples;
     const unsigned pixels = (unsigned)(P.slots / S);  // 64 per tile
     for (unsigned p = blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += gridDim.x * blockDim.x) {

@@ -9,13 +9,25 @@
 //     -DRT_X_LOAD_UNIFORM    ... every lane reads the same line
 //     -DRT_X_LOAD_ONE_LANE   ... only the first lane of the node step makes them
 //   -DRT_X_SALU=n          n extra scalar additions per node step
+//   -DRT_TOP_STATS         the walk over quads tallies, per node step, how many of its lanes sit in the top 1 / 2 / 3 / 4
+//                          quad levels of their tree (the root's quad is level 0) and whether ALL of them do - what a copy
+//                          of the tree's top in LDS could serve.  The level travels in bits 24-28 of the interior
+//                          references (trees of fewer than 2^24 quads only); the frame's last kernel prints the sums
 //
 // The macros use the trace kernel's local names (o, inv, tMax, L0, L1, p, blob4, lane, nodeMask, level, P, ANY, COUNT).
 #ifndef RT_TRACE_PROBES_H
 #define RT_TRACE_PROBES_H
 
+#ifdef RT_TOP_STATS
+#define RT_PROBE_TOP_STATE() unsigned topSteps = 0, topLanes = 0, topIn[4] = {}, uniSteps[5] = {}
+#else
+#define RT_PROBE_TOP_STATE() \
+    do {                     \
+    } while (0)
+#endif
 #ifdef RT_STAMPS
 #define RT_PROBE_STATE()                         \
+    RT_PROBE_TOP_STATE();                          \
     unsigned stampAcc[16] = {}, stampCnt[16] = {}; \
     unsigned long long stampLast = __builtin_amdgcn_s_memtime()
 #define STAMP(i)                                                          \
@@ -37,9 +49,7 @@
             }                                                                                                    \
     } while (0)
 #else
-#define RT_PROBE_STATE() \
-    do {                 \
-    } while (0)
+#define RT_PROBE_STATE() RT_PROBE_TOP_STATE()
 #define STAMP(i) \
     do {         \
     } while (0)
@@ -116,6 +126,74 @@
 #else
 #define RT_PROBE_X_SALU() \
     do {                  \
+    } while (0)
+#endif
+
+#ifdef RT_TOP_STATS
+#define RT_PROBE_QUAD_UNITS(r) ((r)&0xffffffu)
+#define RT_PROBE_QUAD_VOTE()                                                                 \
+    do {                                                                                     \
+        if (kQuad) {                                                                         \
+            const bool node_ = (int)cur >= 0;                                                \
+            const unsigned lvl_ = (cur >> 24) & 31u;                                         \
+            const unsigned long long act_ = __ballot(node_);                                 \
+            uniSteps[4]++;                                                                   \
+            _Pragma("unroll") for (unsigned k_ = 0; k_ < 4; ++k_)                           \
+                if (__ballot(node_ && lvl_ <= k_) == act_) uniSteps[k_]++;                   \
+        }                                                                                    \
+    } while (0)
+#define RT_PROBE_QUAD_STEP()                                                                               \
+    do {                                                                                                   \
+        const unsigned lvl_ = (cur >> 24) & 31u;                                                           \
+        const unsigned nxt_ = (lvl_ < 31u ? lvl_ + 1u : 31u) << 24;                                        \
+        r0 |= RT_REF_IS_LEAF(r0) ? 0u : nxt_;                                                              \
+        r1 |= RT_REF_IS_LEAF(r1) ? 0u : nxt_;                                                              \
+        r2 |= RT_REF_IS_LEAF(r2) ? 0u : nxt_;                                                              \
+        r3 |= RT_REF_IS_LEAF(r3) ? 0u : nxt_;                                                              \
+        topSteps++;                                                                                        \
+        topLanes += 1u; /* per lane: summed over the wavefront at the end */                               \
+        _Pragma("unroll") for (unsigned k_ = 0; k_ < 4; ++k_) {                                           \
+            const bool in_ = lvl_ <= k_;                                                                   \
+            topIn[k_] += in_ ? 1u : 0u;                                                                    \
+        }                                                                                                  \
+    } while (0)
+#define RT_PROBE_QUAD_FLUSH()                                                                              \
+    do {                                                                                                   \
+        if (kQuad) {                                                                                       \
+            unsigned v_[5] = {topLanes, topIn[0], topIn[1], topIn[2], topIn[3]};                            \
+            for (int i_ = 0; i_ < 5; ++i_) {                                                               \
+                for (int off_ = 32; off_ > 0; off_ >>= 1) v_[i_] += __shfl_down(v_[i_], off_, kWave);      \
+                if (lane == 0) atomicAdd(P.ctl + 100 + (ANY ? 16 : 0) + i_, v_[i_]);                       \
+            }                                                                                              \
+            if (lane == 0) {                                                                               \
+                atomicAdd(P.ctl + 105 + (ANY ? 16 : 0), uniSteps[4]);                                      \
+                for (int i_ = 0; i_ < 4; ++i_) atomicAdd(P.ctl + 106 + (ANY ? 16 : 0) + i_, uniSteps[i_]); \
+            }                                                                                              \
+        }                                                                                                  \
+    } while (0)
+#define RT_PROBE_QUAD_REPORT()                                                                                                   \
+    do {                                                                                                                         \
+        if (blockIdx.x == 0 && threadIdx.x == 0)                                                                                 \
+            for (int k_ = 0; k_ < 2; ++k_) {                                                                                     \
+                const uint32_t* c_ = P.ctl + 100 + 16 * k_;                                                                      \
+                printf("top-stats %s: lane-steps %u, of them in quad levels <=0..3: %u %u %u %u; wave steps %u, of them with " \
+                       "ALL lanes in levels <=0..3: %u %u %u %u\n",                                                            \
+                       k_ ? "shadow" : "closest", c_[0], c_[1], c_[2], c_[3], c_[4], c_[5], c_[6], c_[7], c_[8], c_[9]);        \
+            }                                                                                                                    \
+    } while (0)
+#else
+#define RT_PROBE_QUAD_UNITS(r) RT_REF_PAIR_UNITS(r)
+#define RT_PROBE_QUAD_VOTE() \
+    do {                     \
+    } while (0)
+#define RT_PROBE_QUAD_STEP() \
+    do {                     \
+    } while (0)
+#define RT_PROBE_QUAD_FLUSH() \
+    do {                      \
+    } while (0)
+#define RT_PROBE_QUAD_REPORT() \
+    do {                       \
     } while (0)
 #endif
 
