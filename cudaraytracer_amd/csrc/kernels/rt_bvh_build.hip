@@ -14,7 +14,8 @@
 // holds its position, the ranges' centroid bounds are reduced with atomics, and
 // ONE global radix sort per level orders all ranges at once (key = range id in
 // the high word, centroid coordinate in the low word; the range ids grow with
-// the position, so ranges stay where they are).  The reference selects the
+// the position, so ranges stay where they are).  The sort is this file's own
+// (radixSortPairs below: least significant digit first, 8 bits per pass, stable).  The reference selects the
 // median with nth_element; a full sort puts the same primitives on either side
 // whenever the median value is unique, so node boxes and axes are those of the
 // host builder, while the order inside a leaf may differ.
@@ -26,9 +27,10 @@
 // the tree keeps the shape the count dictates; the boxes are right either way, and only ties between primitives
 // with identical box centroids can resolve differently.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 #include <float.h>
 #include <stdint.h>
+
+#include <utility>
 
 #include "../rt_device_format.h"
 
@@ -265,6 +267,157 @@ __global__ void __launch_bounds__(kBlock) recordKernel(int n, int threshold, con
 
 inline int blocksFor(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 
+// ---------------------------------------------------------------------------
+// Stable radix sort of (64-bit key, 32-bit value) pairs, least significant digit first, 8 bits per pass.
+// A pass is three launches: per-tile digit histograms, their exclusive prefix sums (digit-major, so that one sum
+// runs over all tiles of digit 0, then digit 1, ...), and the scatter, in which every tile ranks its keys again and
+// writes them to their places.  A tile is kSortTile consecutive keys; it is walked in rounds of one key per thread,
+// so position order is (round, thread), and a key's rank among the tile's keys of the same digit is
+//   keys of that digit in earlier rounds  +  in lower wavefronts of this round  +  in lower lanes of this wavefront,
+// the last from eight ballots (the lanes whose digit agrees bit by bit), the others from small LDS tables.  Keys of one
+// digit keep their order: the sort is stable, which the build relies on where centroid coordinates tie.
+constexpr int kSortRounds = 16;
+constexpr int kSortTile = kBlock * kSortRounds;
+constexpr int kSortWaves = kBlock / 64;
+
+// lanes of this wavefront (among `valid` ones) whose digit equals this lane's
+__device__ __forceinline__ unsigned long long sameDigit(unsigned digit, bool valid) {
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = ((digit >> b) & 1u) != 0u;
+        const unsigned long long m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+__global__ void __launch_bounds__(kBlock) sortHistKernel(const uint64_t* __restrict__ keys, int n, int shift, uint32_t* __restrict__ hist, int tiles) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * kSortTile;
+    for (int r = 0; r < kSortRounds; ++r) {
+        const size_t i = base + (size_t)r * kBlock + threadIdx.x;
+        const bool valid = i < (size_t)n;
+        const unsigned digit = valid ? (unsigned)(keys[i] >> shift) & 255u : 0u;
+        const unsigned long long peers = sameDigit(digit, valid);
+        // the lowest lane of every group of equal digits adds the group's size: a tile often holds ONE digit (range ids)
+        if (valid && (peers & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0ull) atomicAdd(&h[digit], (uint32_t)__popcll(peers));
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * tiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// One block per digit: exclusive prefix sums over the digit's tile counts, in place; the digit's total goes to total[digit].
+__global__ void __launch_bounds__(kBlock) sortScanTilesKernel(uint32_t* __restrict__ hist, int tiles, uint32_t* __restrict__ total) {
+    __shared__ uint32_t waveSum[kSortWaves];
+    __shared__ uint32_t carry;
+    uint32_t* row = hist + (size_t)blockIdx.x * tiles;
+    if (threadIdx.x == 0) carry = 0u;
+    __syncthreads();
+    for (int at = 0; at < tiles; at += kBlock) {
+        const int i = at + threadIdx.x;
+        const uint32_t v = i < tiles ? row[i] : 0u;
+        uint32_t inc = v;  // inclusive prefix within the wavefront
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t u = __shfl_up(inc, off, 64);
+            if ((int)(threadIdx.x & 63) >= off) inc += u;
+        }
+        if ((threadIdx.x & 63) == 63) waveSum[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        uint32_t before = carry;
+        for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += waveSum[w];
+        if (i < tiles) row[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[blockIdx.x] = carry;
+}
+
+// exclusive prefix sums over the 256 digit totals (one block)
+__global__ void __launch_bounds__(256) sortScanDigitsKernel(uint32_t* __restrict__ total) {
+    __shared__ uint32_t t[256];
+    t[threadIdx.x] = total[threadIdx.x];
+    __syncthreads();
+    uint32_t sum = 0u;
+    for (int d = 0; d < (int)threadIdx.x; ++d) sum += t[d];
+    total[threadIdx.x] = sum;
+}
+
+__global__ void __launch_bounds__(kBlock) sortScatterKernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, int n, int shift,
+                                                            const uint32_t* __restrict__ hist, int tiles, const uint32_t* __restrict__ digitBase,
+                                                            uint64_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut) {
+    __shared__ uint32_t place[256];               // where the tile's next key of each digit goes
+    __shared__ uint32_t inWave[kSortWaves][256];  // this round's keys of each digit, per wavefront
+    place[threadIdx.x] = digitBase[threadIdx.x] + hist[(size_t)threadIdx.x * tiles + blockIdx.x];
+    for (int w = 0; w < kSortWaves; ++w) inWave[w][threadIdx.x] = 0u;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * kSortTile;
+    const unsigned wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << (threadIdx.x & 63)) - 1ull;
+    for (int r = 0; r < kSortRounds; ++r) {
+        const size_t i = base + (size_t)r * kBlock + threadIdx.x;
+        if (base + (size_t)r * kBlock >= (size_t)n) break;  // (the same for the whole block)
+        const bool valid = i < (size_t)n;
+        uint64_t key = 0;
+        uint32_t val = 0;
+        if (valid) {
+            key = keys[i];
+            val = vals[i];
+        }
+        const unsigned digit = valid ? (unsigned)(key >> shift) & 255u : 0u;
+        const unsigned long long peers = sameDigit(digit, valid);
+        if (valid && (peers & below) == 0ull) inWave[wave][digit] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t at = place[digit] + (uint32_t)__popcll(peers & below);
+            for (unsigned w = 0; w < wave; ++w) at += inWave[w][digit];
+            keysOut[at] = key;
+            valsOut[at] = val;
+        }
+        __syncthreads();
+        {
+            // thread d moves digit d's place past this round's keys and clears the round's counts
+            uint32_t add = 0u;
+            for (int w = 0; w < kSortWaves; ++w) {
+                add += inWave[w][threadIdx.x];
+                inWave[w][threadIdx.x] = 0u;
+            }
+            place[threadIdx.x] += add;
+        }
+        __syncthreads();
+    }
+}
+
+// Bytes of scratch radixSortPairs needs for n pairs.
+inline size_t radixSortTempBytes(int n) {
+    const size_t tiles = ((size_t)n + kSortTile - 1) / kSortTile;
+    return (256 * tiles + 256) * sizeof(uint32_t);
+}
+
+// Sorts n pairs by the key bits [0, endBit).  The pairs start in (keysA, valsA) and move between the two buffer pairs
+// pass by pass; returns 0 if the sorted pairs are in (keysA, valsA), 1 if in (keysB, valsB).
+int radixSortPairs(void* temp, uint64_t* keysA, uint64_t* keysB, uint32_t* valsA, uint32_t* valsB, int n, int endBit, hipStream_t stream) {
+    const int tiles = (n + kSortTile - 1) / kSortTile;
+    uint32_t* hist = static_cast<uint32_t*>(temp);
+    uint32_t* total = hist + (size_t)256 * tiles;
+    int in = 0;
+    for (int shift = 0; shift < endBit; shift += 8) {
+        const uint64_t* kin = in ? keysB : keysA;
+        const uint32_t* vin = in ? valsB : valsA;
+        uint64_t* kout = in ? keysA : keysB;
+        uint32_t* vout = in ? valsA : valsB;
+        hipLaunchKernelGGL(sortHistKernel, dim3(tiles), dim3(kBlock), 0, stream, kin, n, shift, hist, tiles);
+        hipLaunchKernelGGL(sortScanTilesKernel, dim3(256), dim3(kBlock), 0, stream, hist, tiles, total);
+        hipLaunchKernelGGL(sortScanDigitsKernel, dim3(1), dim3(256), 0, stream, total);
+        hipLaunchKernelGGL(sortScatterKernel, dim3(tiles), dim3(kBlock), 0, stream, kin, vin, n, shift, hist, tiles, total, kout, vout);
+        in ^= 1;
+    }
+    return in;
+}
+
 }  // namespace
 
 static_assert(sizeof(BuildNode) == sizeof(RtBuildNode), "host and device agree on the work table");
@@ -304,9 +457,7 @@ int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* streamPtr) {
     RTB_HIP(hipMalloc(&nodes, (size_t)job->nodeCnt * sizeof(BuildNode)));
     RTB_HIP(hipMemsetAsync(axisOf, 0, heap, stream));
     RTB_HIP(hipMemcpyAsync(nodes, job->nodes, (size_t)job->nodeCnt * sizeof(BuildNode), hipMemcpyHostToDevice, stream));
-    size_t tempBytes = 0;
-    RTB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tempBytes, keysA, keysB, orderA, orderB, n, 0, 64, stream));
-    RTB_HIP(hipMalloc(&temp, tempBytes));
+    RTB_HIP(hipMalloc(&temp, radixSortTempBytes(n)));
 
     const int grid = blocksFor(n);
     hipLaunchKernelGGL(primBoundsKernel, dim3(grid), dim3(kBlock), 0, stream, n, job->devTriangles, job->devVertices, tight, bmin, bmax);
@@ -317,10 +468,10 @@ int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* streamPtr) {
         hipLaunchKernelGGL(centroidBoundsKernel, dim3(grid), dim3(kBlock), 0, stream, n, thr, level, orderA, bmin, bmax, cb);
         hipLaunchKernelGGL(sortKeyKernel, dim3(grid), dim3(kBlock), 0, stream, n, thr, level, orderA, bmin, bmax, cb, axisOf, keysA);
         // range ids of this level need level + 1 bits above the 32-bit coordinate
-        RTB_HIP(hipcub::DeviceRadixSort::SortPairs(temp, tempBytes, keysA, keysB, orderA, orderB, n, 0, 32 + level + 1, stream));
-        uint32_t* t = orderA;
-        orderA = orderB;
-        orderB = t;
+        if (radixSortPairs(temp, keysA, keysB, orderA, orderB, n, 32 + level + 1, stream)) {
+            std::swap(orderA, orderB);  // the next level reads the order from orderA (and writes its keys over keysA)
+            std::swap(keysA, keysB);
+        }
     }
     float* recs = reinterpret_cast<float*>(job->devNodeRecords);
     hipLaunchKernelGGL(leafBoxKernel, dim3(blocksFor(job->leafCnt)), dim3(kBlock), 0, stream, job->leafCnt, nodes, tight, orderA, bmin, bmax, recs);
