@@ -56,6 +56,14 @@ constexpr unsigned kChunk = RT_CHUNK;  // rays a wavefront takes from the global
 #ifndef RT_TRI_LANES
 #define RT_TRI_LANES 12  // a triangle phase starts once this many lanes wait in a leaf
 #endif
+#ifndef RT_TRACE_VGPR_LIMIT
+#define RT_TRACE_VGPR_LIMIT 88
+#endif
+#if RT_TRACE_VGPR_LIMIT > 0
+#define RT_TRACE_VGPRS __attribute__((amdgpu_num_vgpr(RT_TRACE_VGPR_LIMIT)))
+#else
+#define RT_TRACE_VGPRS
+#endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1  // __launch_bounds__ waves per SIMD for the trace kernel
 #endif
@@ -201,13 +209,23 @@ __device__ __forceinline__ V3 invBiasedOrigin(V3 dir, V3 P, V3 n, float bias) {
 // Level-0 node -> pixel.  With S = opts.samples, node s of this call is lane (s & 63) of sample (s >> 6) % S
 // of local tile (s >> 6) / S; local tile k is frame tile tileFirst + k * tileStride (row-major), or
 // tileOrder[k] when the host supplies an order (the same set of tiles, expensive image regions first).
-__device__ __forceinline__ bool slotPixel(const FrameParams& P, int slot, int& x, int& y) {
+// `single`: true in code compiled for frames of one sample per pixel (no division by the sample count).
+// The tile's row and column come from a multiplication by P.tilesXMagic = floor((2^32 - 1) / tilesX): the product's high
+// word is the quotient or one less (the estimate is short by less than tile / 2^32 < 1), which one comparison settles.
+// (A division by a kernel argument makes the compiler keep a reciprocal in a vector register for the whole kernel.)
+__device__ __forceinline__ bool slotPixel(const FrameParams& P, int slot, int& x, int& y, const bool single = false) {
     const int group = slot >> 6;
-    const int local = P.opts.samples == 1 ? group : group / P.opts.samples;
-    const int tile = P.tileOrder ? P.tileOrder[local] : P.tileFirst + local * P.tileStride;
+    const int local = (single || P.opts.samples == 1) ? group : group / P.opts.samples;
+    const unsigned tile = (unsigned)(P.tileOrder ? P.tileOrder[local] : P.tileFirst + local * P.tileStride);
     const int l = slot & 63;
-    x = (tile % P.tilesX) * RT_TILE + (l & (RT_TILE - 1));
-    y = (tile / P.tilesX) * RT_TILE + (l >> 3);
+    unsigned row = __umulhi(tile, P.tilesXMagic);
+    unsigned col = tile - row * (unsigned)P.tilesX;
+    if (col >= (unsigned)P.tilesX) {
+        col -= (unsigned)P.tilesX;
+        row += 1u;
+    }
+    x = (int)col * RT_TILE + (l & (RT_TILE - 1));
+    y = (int)row * RT_TILE + (l >> 3);
     return x < P.opts.width && y < P.opts.height;
 }
 __device__ __forceinline__ int slotSample(const FrameParams& P, int slot) {
@@ -220,21 +238,27 @@ __device__ __forceinline__ uint32_t pixelSampleBase(const FrameParams& P, int x,
     return P.accum ? (uint32_t) reinterpret_cast<const float*>(P.accum + (size_t)y * P.accumPitch + (size_t)x * 16)[3] : 0u;
 }
 
-// Primary ray direction, cudaTracer/Main.cu:57-75.  With one sample both jitters are exactly 0.0f.
-__device__ __forceinline__ V3 primaryDir(const FrameParams& P, int x, int y, int sample) {
-    const float widthScale = 1.0f / (float)P.opts.width;
-    const float heightScale = 1.0f / (float)P.opts.height;
+// Primary ray direction, cudaTracer/Main.cu:57-75.  With one sample both jitters are exactly 0.0f.  `jitter` is
+// true in the code paths compiled for frames that have a jitter (several samples, or accumulation over frames); the trace
+// kernels of all other frames are compiled without that branch and the registers it holds on to (about 2 % of the
+// rays per second with frames in flight).
+// P.invWidth / P.invHeight are the reference's 1.0f / width and 1.0f / height (Main.cu:57-58), divided on the host: the same
+// correctly rounded quotient, without two vector registers that hold it for the whole kernel.
+__device__ __forceinline__ V3 primaryDir(const FrameParams& P, int x, int y, int sample, const bool jitter = true) {
+    const float widthScale = P.invWidth;
+    const float heightScale = P.invHeight;
     const float ndcX = (2.0f * ((float)x + 0.5f) * widthScale - 1.0f) * P.opts.imageAspectRatio * P.opts.scale;
     const float ndcY = (1.0f - 2.0f * ((float)y + 0.5f) * heightScale) * P.opts.scale;
     float xJitter = 0.0f, yJitter = 0.0f;
-    if (P.opts.samples > 1 || P.accum) {
+    if (jitter && (P.opts.samples > 1 || P.accum)) {
         // accumulating over frames, this call's samples continue the numbering of the pixel's earlier ones
         const uint32_t pixel = (uint32_t)y * (uint32_t)P.opts.width + (uint32_t)x;
         const uint32_t k = pixelSampleBase(P, x, y) + (uint32_t)sample;
         xJitter = rt_sample_jitter(P.sampleSeed, pixel, k, 0u);
         yJitter = rt_sample_jitter(P.sampleSeed, pixel, k, 1u);
     }
-    V3 dir = normalized(mk(ndcX + xJitter * widthScale, ndcY + yJitter * heightScale, 1.0f));
+    // (without a jitter the two sums would add +0, which changes no value: ndcX and ndcY are never -0)
+    V3 dir = jitter ? normalized(mk(ndcX + xJitter * widthScale, ndcY + yJitter * heightScale, 1.0f)) : normalized(mk(ndcX, ndcY, 1.0f));
     const float* C = P.camera;
     dir = mk((dir.x * C[0] + dir.y * C[4]) + dir.z * C[8], (dir.x * C[1] + dir.y * C[5]) + dir.z * C[9],
              (dir.x * C[2] + dir.y * C[6]) + dir.z * C[10]);
@@ -242,12 +266,12 @@ __device__ __forceinline__ V3 primaryDir(const FrameParams& P, int x, int y, int
 }
 
 // Ray of a path node: level 0 is rebuilt from the pixel, deeper nodes are stored.
-__device__ __forceinline__ void nodeRay(const FrameParams& P, int node, V3& o, V3& d) {
+__device__ __forceinline__ void nodeRay(const FrameParams& P, int node, V3& o, V3& d, const bool jitter = true) {
     if (node < P.slots) {
         int x, y;
-        slotPixel(P, node, x, y);
+        slotPixel(P, node, x, y, !jitter);
         o = mk(P.orig);
-        d = primaryDir(P, x, y, slotSample(P, node));
+        d = primaryDir(P, x, y, jitter ? slotSample(P, node) : 0, jitter);
     } else {
         const float4* r = P.secRay + 2 * (size_t)(node - P.slots);
         o = mk(r[0]);
@@ -373,8 +397,9 @@ __device__ __forceinline__ bool triangleSolve(const float4 r0, const float4 r1, 
 // (HIT_DEFERRED / VIS_DEFERRED, counted in CTL_DEFER_*); a second launch with the literal test (LIT = true, `rescue`)
 // walks the marked rays from the start and ends at once when there is none.  Counter launches, small frames and
 // reflection levels use the literal test for every ray, in one launch (launchTrace).
-template <bool ANY, bool COUNT, bool LIT>
-__global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FrameParams P, const int level, const int rescue) {
+// JIT: the frame's primary rays are jittered (closest-hit launches of frames with several samples or accumulation).
+template <bool ANY, bool COUNT, bool LIT, bool JIT>
+__global__ void __launch_bounds__(kWave, RT_MIN_WAVES) RT_TRACE_VGPRS traceKernel(const FrameParams P, const int level, const int rescue) {
     extern __shared__ uint2 s_dyn[];
     const int lane = threadIdx.x;
     // The top of each lane's traversal stack is a ring of ringN (a power of two) entries in LDS: entry e lives in
@@ -548,11 +573,11 @@ __global__ void __launch_bounds__(kWave, RT_MIN_WAVES) traceKernel(const FramePa
                 } else {
                     if (item < P.slots) {
                         int x, y;
-                        valid = slotPixel(P, item, x, y);
+                        valid = slotPixel(P, item, x, y, !JIT);
                         if (valid && COUNT) cPrimary++;
                     }
                     if (valid) {
-                        nodeRay(P, item, o, d);
+                        nodeRay(P, item, o, d, JIT);
                         tMax = 3.402823466e+38f;
                     }
                 }
@@ -1407,7 +1432,7 @@ constexpr bool kCountLit = true;
 // Resident wavefronts per CU of one trace-kernel variant (register and LDS limits).  Asked once per LDS size and kept in a
 // small table; contexts of several host threads (one per GPU) share it under a lock.  The figure is a property of the
 // code object and the LDS size, the same on every gfx950 device.
-template <bool ANY, bool COUNT, bool LIT>
+template <bool ANY, bool COUNT, bool LIT, bool JIT>
 int wavesPerCu(size_t lds) {
     static std::mutex lock;
     static std::map<size_t, int> known;
@@ -1415,11 +1440,11 @@ int wavesPerCu(size_t lds) {
     const auto it = known.find(lds);
     if (it != known.end()) return it->second;
     int perCu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, traceKernel<ANY, COUNT, LIT>, kWave, lds) != hipSuccess || perCu < 1) perCu = 8;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, traceKernel<ANY, COUNT, LIT, JIT>, kWave, lds) != hipSuccess || perCu < 1) perCu = 8;
     perCu = perCu > 32 ? 32 : perCu;
     known[lds] = perCu;
     if (getenv("RT_TRACE_DEBUG"))
-        fprintf(stderr, "traceKernel<%d,%d,%d>: %d resident wavefronts per CU with %zu B LDS\n", (int)ANY, (int)COUNT, (int)LIT, perCu, lds);
+        fprintf(stderr, "traceKernel<%d,%d,%d,%d>: %d resident wavefronts per CU with %zu B LDS\n", (int)ANY, (int)COUNT, (int)LIT, (int)JIT, perCu, lds);
     return perCu;
 }
 
@@ -1428,12 +1453,17 @@ int wavesPerCu(size_t lds) {
 template <bool ANY, bool COUNT, bool LIT>
 void launchOne(const FrameParams& p, int level, int cuCount, hipStream_t s, int rescue) {
     const size_t lds = traceLdsBytes(p.stackLds);
-    int waves = wavesPerCu<ANY, COUNT, LIT>(lds) * cuCount;
+    // shadow rays are rebuilt from their shading contexts: only closest-hit launches have a variant with jitter
+    const bool jit = !ANY && (p.opts.samples > 1 || p.accum != nullptr);
+    int waves = (jit ? wavesPerCu<ANY, COUNT, LIT, !ANY>(lds) : wavesPerCu<ANY, COUNT, LIT, false>(lds)) * cuCount;
     if (waves > p.traceWaves) waves = p.traceWaves;
     // A rescue launch nearly always finds nothing to do: two wavefronts per CU keep it cheap to start and still walk a
     // frame's worth of marked rays, if it ever comes to that, at a twelfth of the full rate.
     if (rescue && waves > 2 * cuCount) waves = 2 * cuCount;
-    hipLaunchKernelGGL((traceKernel<ANY, COUNT, LIT>), dim3(waves), dim3(kWave), lds, s, p, level, rescue);
+    if (jit)
+        hipLaunchKernelGGL((traceKernel<ANY, COUNT, LIT, !ANY>), dim3(waves), dim3(kWave), lds, s, p, level, rescue);
+    else
+        hipLaunchKernelGGL((traceKernel<ANY, COUNT, LIT, false>), dim3(waves), dim3(kWave), lds, s, p, level, rescue);
 }
 template <bool ANY, bool COUNT>
 void launchTrace(const FrameParams& p, int level, int cuCount, hipStream_t s) {
@@ -1457,12 +1487,15 @@ void launchTrace(const FrameParams& p, int level, int cuCount, hipStream_t s) {
 int rtk_trace_waves_per_cu(int stackLds) {
     const size_t lds = traceLdsBytes(stackLds);
     // the largest residency of the variants: each launch takes its own, this one sizes the spill buffer
-    int w = wavesPerCu<false, false, false>(lds);
-    w = std::max(w, wavesPerCu<true, false, false>(lds));
-    w = std::max(w, wavesPerCu<false, true, kCountLit>(lds));
-    w = std::max(w, wavesPerCu<true, true, kCountLit>(lds));
-    w = std::max(w, wavesPerCu<false, false, true>(lds));
-    w = std::max(w, wavesPerCu<true, false, true>(lds));
+    int w = wavesPerCu<false, false, false, false>(lds);
+    w = std::max(w, wavesPerCu<true, false, false, false>(lds));
+    w = std::max(w, wavesPerCu<false, true, kCountLit, false>(lds));
+    w = std::max(w, wavesPerCu<true, true, kCountLit, false>(lds));
+    w = std::max(w, wavesPerCu<false, false, true, false>(lds));
+    w = std::max(w, wavesPerCu<true, false, true, false>(lds));
+    w = std::max(w, wavesPerCu<false, false, false, true>(lds));
+    w = std::max(w, wavesPerCu<false, true, kCountLit, true>(lds));
+    w = std::max(w, wavesPerCu<false, false, true, true>(lds));
     return w;
 }
 

@@ -1339,6 +1339,9 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
     p.tileCost = ctx->tileCost;
     p.tilesX = (opts->width + RT_TILE - 1) / RT_TILE;
     p.tilesY = (opts->height + RT_TILE - 1) / RT_TILE;
+    p.tilesXMagic = (uint32_t)(0xFFFFFFFFull / (unsigned long long)p.tilesX);
+    p.invWidth = 1.0f / (float)opts->width;
+    p.invHeight = 1.0f / (float)opts->height;
     const long long tiles = (long long)p.tilesX * p.tilesY;
     const int tileFirst = aux ? aux->tileFirst : 0;
     const int tileStride = aux && aux->tileStride > 0 ? aux->tileStride : 1;

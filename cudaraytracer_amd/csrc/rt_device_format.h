@@ -198,6 +198,8 @@ struct FrameParams {
     uint32_t* tileCost;                      // optional [tilesX * tilesY]: counter launches add each tile's box + triangle tests
     // tile shard
     int32_t tilesX, tilesY;
+    uint32_t tilesXMagic;                    // floor((2^32 - 1) / tilesX): tile -> (row, column) without a division
+    float invWidth, invHeight;               // 1.0f / width, 1.0f / height as the reference forms them (cudaTracer/Main.cu:57-58)
     int32_t tileFirst, tileStride, tileCnt;  // this call renders tiles tileFirst + k*tileStride, k < tileCnt
     const int32_t* tileOrder;                // optional [tileCnt]: frame tile of local tile k (overrides the arithmetic rule)
     int32_t slots;                           // tileCnt * samples * 64 level-0 nodes
