@@ -528,7 +528,8 @@ def main():
         bvh_bytes = 32 * d.nodeCnt + 64 * d.shapeCnt + sum(32 * d.meshes[i].nodeCnt + 48 * d.meshes[i].triangleCnt for i in range(d.meshCnt))
         compulsory = bvh_bytes + HIT_RECORD_BYTES * traced // world
         wl_key = f"{args.scene}-{args.size}-{w}x{h}-l{args.lights}-d{args.max_depth}"
-        prof = profile_table(wl_key).get("traceKernel<false, false, false>", {}) if world == 1 else {}
+        # (the closest-hit kernel of frames without jitter: template arguments ANY, COUNT, LIT, JIT all false)
+        prof = profile_table(wl_key).get("traceKernel<false, false, false, false>", {}) if world == 1 else {}
         prof_src = f"profiles/traffic.json <- profiles/{PROFILE_ROUND}: separate rocprofv3 --pmc passes of `bench.py --frames-in-flight 1`, NOT this run"
         ms_per_step = elapsed / args.steps * 1e3
         out = {
@@ -574,7 +575,7 @@ def main():
             "kernel_ms_in_flight": dict(zip(("frame", "trace_closest", "shade", "trace_shadow", "rest"), in_flight_stage)),
             # The dominant kernel is the closest-hit trace of the primary rays.  What bounds it is fp32 vector work and the
             # latency of its dependent loads, not HBM: its working set (BVH + triangle records) stays in L2 / Infinity Cache.
-            "roofline": {"bound": "valu_fp32", "kernel": "traceKernel<false,false,false> (closest hit, primary rays)",
+            "roofline": {"bound": "valu_fp32", "kernel": "traceKernel<false,false,false,false> (closest hit, primary rays)",
                          "achieved": achieved, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_VECTOR_PEAK_TFLOPS,
                          "algorithmic_flops_per_launch": closest_flops // world,
                          "launch_ms": closest_ms,
@@ -602,7 +603,7 @@ def main():
                          "instructions": {"valu_per_launch": prof.get("valu_insts_per_launch"),
                                           "valu_per_box_pair_or_triangle_phase": None,
                                           "source": prof_src if prof else None},
-                         "other_kernels": {"traceKernel<true,false,false> (shadow, any hit)": {"achieved": tflops(shadow_flops, shadow_ms), "unit": "TFLOP/s",
+                         "other_kernels": {"traceKernel<true,false,false,false> (shadow, any hit)": {"achieved": tflops(shadow_flops, shadow_ms), "unit": "TFLOP/s",
                                                                                          "algorithmic_flops_per_launch": shadow_flops // world,
                                                                                          "launch_ms": shadow_ms},
                                            "whole frame, by wall clock, frames in flight": {"achieved": tflops(closest_flops + shadow_flops, ms_per_step),

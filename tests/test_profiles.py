@@ -37,7 +37,7 @@ def test_traffic_table_equals_the_committed_summary():
     traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
     assert workload in traffic
     assert traffic[workload] == tables
-    dominant = traffic[workload]["traceKernel<false, false, false>"]
+    dominant = traffic[workload]["traceKernel<false, false, false, false>"]
     assert dominant["hbm_bytes_per_launch"] == 2 * dominant["fetch_size_bytes_raw"] + dominant["write_size_bytes"]
     assert dominant["valu_insts_per_launch"] > 0
 
@@ -47,4 +47,4 @@ def test_kernel_stats_of_the_round_are_committed():
     stats = os.path.join(ROOT, "profiles", rnd, "trace_kernel_stats.csv")
     assert os.path.exists(stats)
     text = open(stats).read()
-    assert "traceKernel<false, false, false>" in text and "AverageNs" in text
+    assert "traceKernel<false, false, false, false>" in text and "AverageNs" in text
