@@ -28,6 +28,8 @@ ap.add_argument("--waves", type=int, default=0)
 ap.add_argument("--split", type=int, default=-1, help="rt_set_box_test_split: level-0 traces of at least this many rays run as two launches")
 ap.add_argument("--cost-order", action="store_true", help="tiles in order of falling cost, measured by a counter frame (rt_set_tile_list)")
 ap.add_argument("--tile-order", type=int, default=-1)
+ap.add_argument("--cost-first", type=float, default=0.0,
+                help="with --cost-order: only this fraction of the tiles (the most expensive) goes first, in order of falling cost; the rest keeps the centre-out order")
 ap.add_argument("--device-bvh", action="store_true")
 ap.add_argument("--sah", action="store_true", help="mesh BVHs cut by the binned surface-area heuristic (host build)")
 ap.add_argument("--leaf", type=int, default=0, help="most triangles in a leaf (0: builder default)")
@@ -101,6 +103,14 @@ with rt.Context(0) as ctx:
         ctx.set_tile_cost_buffer(None)
         costs = ctx.download(cost, (tx * ty,), np.uint32).astype(np.int64)
         order = np.argsort(-costs, kind="stable")[:: 1]
+        if a.cost_first > 0.0:
+            head = order[: max(1, int(len(order) * a.cost_first))]
+            ys, xs = np.divmod(np.arange(tx * ty), tx)
+            d2 = (xs * 16 + 8 - a.width) ** 2 + (ys * 16 + 8 - a.height) ** 2  # the library's centre-out key
+            centre_out = np.lexsort((np.arange(tx * ty), d2))
+            taken = np.zeros(tx * ty, dtype=bool)
+            taken[head] = True
+            order = np.concatenate([head, centre_out[~taken[centre_out]]])
         order = order[a.stride - 1:: a.stride] if a.stride > 1 else order
         ctx.set_tile_list(order)
         print(f"  cost order: most expensive tile {costs.max()} tests, median {int(np.median(costs))}, cheapest {costs.min()}")
