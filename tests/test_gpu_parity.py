@@ -591,6 +591,31 @@ def test_ten_million_triangle_heightfield_at_4k(gpu_ctx, oracle):
         gpu_ctx.free_scene(dscene)
 
 
+@pytest.mark.parametrize("label,name,w,h,size,lights,depth", [
+    ("cfg 1: 16x16 cube meshes under a scene BVH", "cubes", 640, 480, 16, 4, 5),
+    ("cfg 3: barrel instances, textured plane, mirror and glass balls", "barrel", 1920, 1080, 0, 10, 2),
+    ("cfg 5: default-scene analogue", "mixed", 1920, 1080, 0, 16, 4),
+])
+def test_other_workloads_at_full_size(gpu_ctx, oracle, synthetic_assets, label, name, w, h, size, lights, depth):
+    """The bench's other workloads at the sizes it runs them (mesh and texture files: stand-ins of the reference's
+    shape): the whole frame against the oracle - every hit key, the radiance with its NaN pixels, integer-equal test and
+    ray counters through all reflection levels - and the plain build's frame against the counter build's."""
+    scene = rt.HostScene(name, w, h, size, lights, depth, asset_dir=None if name == "cubes" else synthetic_assets, tight_bvh=True)
+    dscene = gpu_ctx.upload(scene)
+    try:
+        rgba, keys, cnt = gpu_ctx.render_frame(scene, dscene, want_keys=True, want_counters=True)
+        ref_rgba, ref_keys, ref_cnt = oracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=16, shadow_any_hit=True)
+        r = assert_parity(rgba, keys, ref_rgba, ref_keys)
+        assert r["key_mismatches"] == 0 and cnt == ref_cnt, (label, r, cnt, ref_cnt)
+        assert cnt["primary"] == w * h
+        if depth > 0 and name != "cubes":
+            assert cnt["secondary"] > 0  # the mirror and glass materials did spawn rays
+        plain = gpu_ctx.render_frame(scene, dscene, want_keys=True)
+        assert np.array_equal(plain[1], keys) and np.array_equal(plain[0], rgba, equal_nan=True)
+    finally:
+        gpu_ctx.free_scene(dscene)
+
+
 @pytest.mark.parametrize("name,size,lights,depth", [("soup", 50000, 2, 0), ("mixed", 0, 2, 2)])
 def test_8k_frame(gpu_ctx, oracle, name, size, lights, depth):
     """7680x4320: 33 M pixels, with the mixed scene up to 100 M path nodes - index arithmetic at its largest.  Rows
