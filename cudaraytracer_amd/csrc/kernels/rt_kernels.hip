@@ -56,13 +56,8 @@ constexpr unsigned kChunk = RT_CHUNK;  // rays a wavefront takes from the global
 #ifndef RT_TRI_LANES
 #define RT_TRI_LANES 12  // a triangle phase starts once this many lanes wait in a leaf
 #endif
-#ifndef RT_TRACE_VGPR_LIMIT
-#define RT_TRACE_VGPR_LIMIT 88
-#endif
-#if RT_TRACE_VGPR_LIMIT > 0
-#define RT_TRACE_VGPRS __attribute__((amdgpu_num_vgpr(RT_TRACE_VGPR_LIMIT)))
-#else
-#define RT_TRACE_VGPRS
+#ifndef RT_MIN_WAVES_ANY
+#define RT_MIN_WAVES_ANY 1  // the same for the shadow-ray variants
 #endif
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1  // __launch_bounds__ waves per SIMD for the trace kernel
@@ -399,7 +394,7 @@ __device__ __forceinline__ bool triangleSolve(const float4 r0, const float4 r1, 
 // reflection levels use the literal test for every ray, in one launch (launchTrace).
 // JIT: the frame's primary rays are jittered (closest-hit launches of frames with several samples or accumulation).
 template <bool ANY, bool COUNT, bool LIT, bool JIT>
-__global__ void __launch_bounds__(kWave, RT_MIN_WAVES) RT_TRACE_VGPRS traceKernel(const FrameParams P, const int level, const int rescue) {
+__global__ void __launch_bounds__(kWave, ANY ? RT_MIN_WAVES_ANY : RT_MIN_WAVES) traceKernel(const FrameParams P, const int level, const int rescue) {
     extern __shared__ uint2 s_dyn[];
     const int lane = threadIdx.x;
     // The top of each lane's traversal stack is a ring of ringN (a power of two) entries in LDS: entry e lives in
