@@ -452,6 +452,17 @@ def main():
     elapsed, issue_s, in_flight_stage = timed_region(args.steps, args.warmup)
     alone_stage, alone_wall = alone() if nf > 1 else (in_flight_stage, elapsed / args.steps * 1e3)
 
+    # ---- throughput against latency: the same frames with fewer of them in flight (one GPU, after the timed region) ----
+    sweep = None
+    if not multi and not args.no_others:
+        sweep = []
+        for k in (2, 3, 4, 6):
+            if k >= nf:
+                continue
+            wall_k, ev_k = time_frames(ctx, lambda s_: ctx.render(dscene, opts, camera_ref, s_.data_ptr(), pitch), 60, k, surfaces)
+            sweep.append({"frames_in_flight": k, "Mrays_per_s": rays / wall_k / 1e3, "ms_per_frame": wall_k, "frame_latency_ms": ev_k[0]})
+        ctx.set_frames_in_flight(nf)
+
     # ---- the gathered frame against the same frame rendered whole on rank 0 (untimed) ----
     gather_check = None
     if multi and rank == 0:
@@ -562,6 +573,7 @@ def main():
                                                          else "tiles packed / assembled by torch index arithmetic"),
                        "frames_in_flight": nf,
                        "frame_latency_ms_with_frames_in_flight": in_flight_stage[0],
+                       "fewer_frames_in_flight": sweep,
                        "in_order": {"ms_per_frame": frame_ms, "wall_ms_per_frame": alone_wall, "Mrays_per_s": rays / alone_wall / 1e3,
                                     "note": "one frame in flight: every frame starts after the previous one has finished, as the reference's "
                                             "cudamain + cudaDeviceSynchronize does; `value` overlaps consecutive frames instead"},
