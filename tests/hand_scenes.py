@@ -25,8 +25,8 @@ FLAT_NORMAL = [[(128, 128, 255)]]
 
 
 class Mesh:
-    """One mesh: triangles as lists of three vertices {pos, uv, normal}; tangent and bitangent are zero, so the shading
-    normal is the interpolated vertex normal whatever the normal map holds.  `nodes`: None = all triangles in one leaf,
+    """One mesh: triangles as lists of three vertices {pos, uv, normal, tangent, bitangent}; tangent and bitangent default
+    to zero, so that the shading normal is the interpolated vertex normal whatever the normal map holds.  `nodes`: None = all triangles in one leaf,
     else a list of (bbmin, bbmax, offset, primCnt, axis) in the reference's depth-first order."""
 
     def __init__(self, triangles, material=DIFFUSE, ior=1.3, ks=0.0, spec_exp=25.0, diffuse=WHITE, specular=BLACK, normals=FLAT_NORMAL,
@@ -39,8 +39,8 @@ class Mesh:
         self.device_bvh = device_bvh  # no nodes at all: rt_scene_upload builds the BVH on the GPU
 
 
-def tri(p0, p1, p2, uv=((0, 0), (1, 0), (0, 1)), normal=(0, 0, -1)):
-    return [{"pos": p, "uv": t, "normal": normal} for p, t in zip((p0, p1, p2), uv)]
+def tri(p0, p1, p2, uv=((0, 0), (1, 0), (0, 1)), normal=(0, 0, -1), tangent=(0, 0, 0), bitangent=(0, 0, 0)):
+    return [{"pos": p, "uv": t, "normal": normal, "tangent": tangent, "bitangent": bitangent} for p, t in zip((p0, p1, p2), uv)]
 
 
 class Scene:
@@ -63,6 +63,8 @@ class Scene:
                     v.position[:] = c["pos"]
                     v.texCoord[:] = c["uv"]
                     v.normal[:] = c["normal"]
+                    v.tangent[:] = c.get("tangent", (0, 0, 0))
+                    v.bitangent[:] = c.get("bitangent", (0, 0, 0))
                     tris[t].i[k] = 3 * t + k
                     pos.append(c["pos"])
             pos = np.asarray(pos, dtype=np.float32)
@@ -212,6 +214,37 @@ def probes():
                                                         (5.0 / 3, 5.0 / 3, 5.0 / 3), (0, 0, 1, 2))
     # two identical triangles in one leaf: equal t, the later one replaces the earlier (t <= tMax, Mesh.cuh:203)
     P["equal_t_later_triangle_wins"] = (Scene(1, 1, [Mesh([tri(*FRONT), tri(*FRONT)])], lights=LIGHT_AT_CAMERA), (1.0, 1.0, 1.0), (0, 3, 4, 5))
+
+    # ---- shading (cudaTracer/tracer.cu:144-200).  The hit is always (0, 0, 5) with n = (0, 0, -1), dir = (0, 0, 1).
+    # Blinn-Phong with the light at the camera: L = (0, 0, -1), half vector = normalize(L - dir) = (0, 0, -1), its dot
+    # with n is 1, 1^25 = 1; light component = 1 * 5 / 5 = 1.  Black diffuse map, specular map red channel 128:
+    # pixel = 0 + 1 * (128 / 255) * 1 on all three channels (the mask is a scalar: Mesh.cuh getSpecularMask takes [X])
+    P["specular_mask_scales_the_highlight"] = (Scene(1, 1, [Mesh([tri(*FRONT)], diffuse=BLACK, specular=[[(128, 7, 9)]])], lights=LIGHT_AT_CAMERA),
+                                               (128 / 255,) * 3, (0, 0, 1, 2))
+    # light at (3, 0, 1): L = (3, 0, -4) / 5, lambert = 0.8, light component 5 / 5 = 1; half vector = normalize((0.6, 0, -1.8)),
+    # (h . n)^2 = 3.24 / 3.6 = 0.9 with shininess 2; white maps: pixel = 1 * 0.8 * 1 + 1 * 1 * 0.9 = 1.7
+    P["lambert_and_blinn_phong_off_axis"] = (Scene(1, 1, [Mesh([tri(*FRONT)], specular=WHITE, spec_exp=2.0)], lights=[((3, 0, 1), (1, 1, 1), 5.0)]),
+                                             (1.7, 1.7, 1.7), (0, 0, 1, 2))
+    # two lights, summed in table order, each falling off with 1 / distance (not its square): at the camera 5 / 5 = 1,
+    # at (0, 0, 2.5) with intensity (1, 0.5, 0.25): 5 / 2.5 = 2 times the intensity: pixel = (1 + 2, 1 + 1, 1 + 0.5)
+    P["two_lights_with_linear_falloff"] = (Scene(1, 1, [Mesh([tri(*FRONT)])], lights=[((0, 0, 0), (1, 1, 1), 5.0), ((0, 0, 2.5), (1, 0.5, 0.25), 5.0)]),
+                                           (3.0, 2.0, 1.5), (0, 0, 1, 2))
+    # gamma (cudaTracer/Main.cu:86-92): pixel = radiance^(1 / 2.2); radiance = the diffuse texel 64 / 255
+    P["gamma_is_a_power_of_one_over_2_2"] = (Scene(1, 1, [Mesh([tri(*FRONT)], diffuse=[[(64, 64, 64)]])], lights=LIGHT_AT_CAMERA, gamma=1),
+                                             ((64 / 255) ** (1 / 2.2),) * 3, (0, 0, 1, 2))
+    # normal map (cudaTracer/Mesh.cuh:73-95): texel (255, 255, .) -> (1, 1) after * 2 - 1; n' = normalize(n + 1 * t + 1 * b) with
+    # t = (1, 0, 0), b = (0, 1, 0): (1, 1, -1) / sqrt 3; light at the camera: lambert = 1 / sqrt 3
+    P["normal_map_tilts_the_normal"] = (Scene(1, 1, [Mesh([tri(*FRONT, tangent=(1, 0, 0), bitangent=(0, 1, 0))], normals=[[(255, 255, 255)]])],
+                                              lights=LIGHT_AT_CAMERA), (3 ** -0.5,) * 3, (0, 0, 1, 2))
+    # A mesh transform that scales through w (Mat44::scale(s) puts 1 / s into [3][3], cudaTracer/Mat.cuh:381-386):
+    # Mesh::intersect divides the ORIGIN by w and leaves the direction alone (Mesh.cuh:115-117, Mat.cuh:127-149).  With
+    # w = 2 and the ray from (0, 0, -5): object-space origin (0, 0, -2.5), direction (0, 0, 1); a triangle in the object's
+    # plane z = 2.5 is hit at t = 5, which is also the world distance: world hit point (0, 0, 0), light at the camera 5
+    # away: pixel = 5 / 5 = 1.  (Were the direction scaled too, or the origin not divided, t would be 7.5 or 2.5.)
+    lower = tuple((x, y, 2.5) for x, y, _ in FRONT)
+    P["mesh_transform_divides_the_origin_by_w_only"] = (
+        Scene(1, 1, [Mesh([tri(*lower)], transform_inverse=np.diag([1.0, 1.0, 1.0, 2.0]))], lights=[((0, 0, -5), (1, 1, 1), 5.0)], origin=(0, 0, -5)),
+        (1.0, 1.0, 1.0), (0, 0, 1, 2))
     return P
 
 
