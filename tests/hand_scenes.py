@@ -245,6 +245,36 @@ def probes():
     P["mesh_transform_divides_the_origin_by_w_only"] = (
         Scene(1, 1, [Mesh([tri(*lower)], transform_inverse=np.diag([1.0, 1.0, 1.0, 2.0]))], lights=[((0, 0, -5), (1, 1, 1), 5.0)], origin=(0, 0, -5)),
         (1.0, 1.0, 1.0), (0, 0, 1, 2))
+    # two identical spheres in the one scene leaf: equal t, the sphere test rejects only t0 > tMax (Sphere.cuh:48-51), so the
+    # shape tested later wins (Scene.cuh:47-50): the pixel has the second sphere's colour, 5 / 4 * colour
+    P["equal_t_later_sphere_wins"] = (Scene(1, 1, spheres=[((0, 0, 5), 1.0, DIFFUSE, 1.3, (0.4, 0.2, 0.1)), ((0, 0, 5), 1.0, DIFFUSE, 1.3, (0.1, 0.2, 0.4))],
+                                            lights=LIGHT_AT_CAMERA), (0.125, 0.25, 0.5), (1, -1, -1, -1))
+    # depth limit (tracer.cu:16-18): with maxDepth 0 the mirror's reflected ray is at depth 1 and returns the background
+    # without looking at the scene - a lit sphere sits right in its way (the mirror faces the camera: the reflected ray
+    # comes straight back) - times kr = 0.04
+    P["depth_limit_returns_the_background"] = (Scene(1, 1, [Mesh([tri(*FRONT)], material=MIRROR, ior=1.5)],
+                                                     spheres=[((0, 0, 2), 0.5, DIFFUSE, 1.3, (1.0, 1.0, 1.0))], lights=[((0, 0, 3.5), (1, 1, 1), 5.0)],
+                                                     max_depth=0, origin=(0, 0, 3)),
+                                               tuple(0.04 * c for c in BG), (0, 0, 1, 2))
+    # the shadow ray's origin is biased to the side the VIEW direction comes from (tracer.cu:175,202-208), not the light's:
+    # shading normal (0, 0, 1) pointing away from the camera, light behind the triangle at (0, 0, 10): lambert = 1, but
+    # dir . n > 0 puts the origin at z = 5 - bias, in front of the triangle, and the ray towards +z meets the triangle
+    # itself (front-facing for that direction, t = bias >= 0): in shadow, black
+    P["shadow_origin_follows_the_view_side"] = (Scene(1, 1, [Mesh([tri(*FRONT, normal=(0, 0, 1))])], lights=[((0, 0, 10), (1, 1, 1), 5.0)]),
+                                                (0.0, 0.0, 0.0), (0, 0, 1, 2))
+    # mirror turned 45 degrees about y, shading normal (-1, 0, -1) / sqrt 2: reflected direction dir - 2 (dir . n) n = (-1, 0, 0)
+    # (tracer.cu:134-142, Vec.cuh:249-251), which meets a sphere of radius 1 at (-6, 0, 5) in (-5, 0, 5).  The sphere is lit by a
+    # light at (-2, 0, 5), 3 away along its normal: radiance = 5 / 3 * colour.  (A light AT the mirror point would be hidden
+    # by the mirror itself, which is front-facing for the sphere's shadow ray.)  Fresnel at 45 degrees into n = 1.5
+    # (tracer.cu:67-89, the textbook equations): cos_t = sqrt(1 - 0.5 / 2.25); kr = (Rs^2 + Rp^2) / 2
+    ci, ct = 0.5 ** 0.5, (1 - 0.5 / 2.25) ** 0.5
+    rs, rp = (1.5 * ci - ct) / (1.5 * ci + ct), (ci - 1.5 * ct) / (ci + 1.5 * ct)
+    kr45 = (rs * rs + rp * rp) / 2
+    slanted = ((-3, -3, 8), (-3, 6, 8), (6, -3, -1))  # the plane x + z = 5 through (0, 0, 5); det > 0 for rays along +z
+    r2 = 0.5 ** 0.5
+    P["mirror_at_45_degrees"] = (Scene(1, 1, [Mesh([tri(*slanted, normal=(-r2, 0, -r2))], material=MIRROR, ior=1.5)],
+                                       spheres=[((-6, 0, 5), 1.0, DIFFUSE, 1.3, (0.8, 0.4, 0.2))], lights=[((-2, 0, 5), (1, 1, 1), 5.0)], max_depth=1),
+                                 tuple(kr45 * 5 / 3 * c for c in (0.8, 0.4, 0.2)), (0, 0, 1, 2))
     return P
 
 
@@ -261,6 +291,8 @@ BILINEAR = [
     ((0.5, 0.25, 1), (0.5, 0.5, 0)), ((0.25, 0.5, 1), (0.5, 0, 0.5)), ((0.5, 0.5, 1), (0.5, 0.5, 0.5)),  # midway: the mean
     ((0.0, 0.0, 1), (1, 0, 0)), ((1.0, 1.0, 1), (1, 1, 1)), ((1.0, 0.0, 1), (0, 1, 0)),  # CLAMP repeats the edge texel
     ((0.0, 0.25, 0), (0.5, 0.5, 0)),  # WRAP: the left neighbour of texel 0 is texel 1
+    ((1.25, 0.25, 0), (1, 0, 0)), ((1.75, 1.75, 0), (1, 1, 1)),  # WRAP beyond 1: the map repeats (texel centres of the second period)
+    ((1.25, 0.25, 1), (0, 1, 0)),  # CLAMP beyond 1: the last texel of the row
 ]
 
 
