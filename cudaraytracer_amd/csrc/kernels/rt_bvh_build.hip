@@ -279,6 +279,7 @@ inline int blocksFor(long long n) { return (int)((n + kBlock - 1) / kBlock); }
 constexpr int kSortRounds = 16;
 constexpr int kSortTile = kBlock * kSortRounds;
 constexpr int kSortWaves = kBlock / 64;
+static_assert(kBlock == 256, "one thread per digit value: the histogram and place tables are filled and scanned by thread index");
 
 // lanes of this wavefront (among `valid` ones) whose digit equals this lane's
 __device__ __forceinline__ unsigned long long sameDigit(unsigned digit, bool valid) {
