@@ -19,7 +19,7 @@
 #define RT_TRACE_PROBES_H
 
 #ifdef RT_TOP_STATS
-#define RT_PROBE_TOP_STATE() unsigned topSteps = 0, topLanes = 0, topIn[4] = {}, uniSteps[5] = {}
+#define RT_PROBE_TOP_STATE() unsigned topSteps = 0, topLanes = 0, topIn[4] = {}, uniSteps[5] = {}, sameQuad[4] = {}
 #else
 #define RT_PROBE_TOP_STATE() \
     do {                     \
@@ -138,6 +138,17 @@
             const unsigned lvl_ = (cur >> 24) & 31u;                                         \
             const unsigned long long act_ = __ballot(node_);                                 \
             uniSteps[4]++;                                                                   \
+            {                                                                                \
+                /* distinct quads among the step's lanes: 1, 2, 3-4, more */                  \
+                unsigned long long left_ = act_;                                             \
+                unsigned distinct_ = 0;                                                      \
+                while (left_ != 0ull && distinct_ < 5u) {                                    \
+                    const unsigned q_ = __builtin_amdgcn_readlane(cur & 0xffffffu, __ffsll((long long)left_) - 1); \
+                    left_ &= ~__ballot(node_ && (cur & 0xffffffu) == q_);                    \
+                    ++distinct_;                                                             \
+                }                                                                            \
+                sameQuad[distinct_ <= 1u ? 0 : (distinct_ == 2u ? 1 : (distinct_ <= 4u ? 2 : 3))]++; \
+            }                                                                                \
             _Pragma("unroll") for (unsigned k_ = 0; k_ < 4; ++k_)                           \
                 if (__ballot(node_ && lvl_ <= k_) == act_) uniSteps[k_]++;                   \
         }                                                                                    \
@@ -168,6 +179,7 @@
             if (lane == 0) {                                                                               \
                 atomicAdd(P.ctl + 105 + (ANY ? 16 : 0), uniSteps[4]);                                      \
                 for (int i_ = 0; i_ < 4; ++i_) atomicAdd(P.ctl + 106 + (ANY ? 16 : 0) + i_, uniSteps[i_]); \
+                for (int i_ = 0; i_ < 4; ++i_) atomicAdd(P.ctl + 110 + (ANY ? 16 : 0) + i_, sameQuad[i_]); \
             }                                                                                              \
         }                                                                                                  \
     } while (0)
@@ -177,8 +189,9 @@
             for (int k_ = 0; k_ < 2; ++k_) {                                                                                     \
                 const uint32_t* c_ = P.ctl + 100 + 16 * k_;                                                                      \
                 printf("top-stats %s: lane-steps %u, of them in quad levels <=0..3: %u %u %u %u; wave steps %u, of them with " \
-                       "ALL lanes in levels <=0..3: %u %u %u %u\n",                                                            \
-                       k_ ? "shadow" : "closest", c_[0], c_[1], c_[2], c_[3], c_[4], c_[5], c_[6], c_[7], c_[8], c_[9]);        \
+                       "ALL lanes in levels <=0..3: %u %u %u %u; steps whose lanes sit in 1 / 2 / 3-4 / more distinct quads: %u %u %u %u\n", \
+                       k_ ? "shadow" : "closest", c_[0], c_[1], c_[2], c_[3], c_[4], c_[5], c_[6], c_[7], c_[8], c_[9], c_[10], c_[11], c_[12], \
+                       c_[13]);                                                                                                  \
             }                                                                                                                    \
     } while (0)
 #else
