@@ -199,3 +199,27 @@ def test_host_only_packing_rejects_a_mesh_without_nodes(rtlib):
     m = s.desc.contents.meshes[0]
     assert m.nodeCnt == 0 and not m.nodes
     expect_error(rtlib, s.desc, RT_ERR_INVALID, "without BVH nodes")
+
+
+def test_tile_row_and_column_by_multiplication():
+    """The kernels split a tile index into row and column with P.tilesXMagic = floor((2^32 - 1) / tilesX): the high word of
+    tile * magic is the row or one less, one comparison settles it (rt_kernels.hip slotPixel).  The same arithmetic here, for
+    every tile count per row up to 4096 at the values where an estimate could be off, and for all tiles of a few frames."""
+    import numpy as np
+
+    def split(tile, d):
+        magic = np.uint64(0xFFFFFFFF // d)
+        row = (tile.astype(np.uint64) * magic) >> np.uint64(32)
+        col = tile.astype(np.int64) - row.astype(np.int64) * d
+        fix = col >= d
+        return row.astype(np.int64) + fix, col - fix * d
+
+    for d in range(1, 4097):
+        ks = np.array([0, 1, 2, 1000, 4095, 4096, (1 << 20) // d, (1 << 24) // d, (1 << 31) // d - 1], dtype=np.int64)
+        tiles = np.unique(np.clip(np.concatenate([ks * d - 1, ks * d, ks * d + 1, ks * d + d - 1]), 0, (1 << 31) - 1)).astype(np.uint32)
+        row, col = split(tiles, d)
+        assert np.array_equal(row, tiles.astype(np.int64) // d) and np.array_equal(col, tiles.astype(np.int64) % d), d
+    for d in (1, 3, 80, 240, 480, 960, 1000):
+        tiles = np.arange(0, 1 << 21, dtype=np.uint32)
+        row, col = split(tiles, d)
+        assert np.array_equal(row, tiles.astype(np.int64) // d) and np.array_equal(col, tiles.astype(np.int64) % d), d
