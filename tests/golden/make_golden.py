@@ -112,7 +112,7 @@ def eval_texture(texels, uv, mode):
     out = np.zeros((len(uv), 3), dtype=np.float32)
     o3 = (C.c_float * 3)()
     for i, (u, v) in enumerate(uv):
-        lib.oracle_tex_sample(C.addressof(t), float(u), float(v), o3)
+        lib.oracle_tex_sample(C.byref(t), float(u), float(v), o3)
         out[i] = list(o3)
     return out
 

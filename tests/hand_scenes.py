@@ -155,6 +155,10 @@ BACK = (FRONT[0], FRONT[2], FRONT[1])
 LIGHT_AT_CAMERA = [((0, 0, 0), (1, 1, 1), 5.0)]
 
 
+# relative tolerance of a probe's pixel where the derivation's numbers are not exact in fp32 (default 2e-6)
+RTOL = {"refract_oblique_incidence_follows_snell": 1e-5}
+
+
 def probes():
     """name -> (Scene, expected centre pixel rgb or None, expected centre hit key or None)."""
     P = {}
@@ -275,7 +279,35 @@ def probes():
     P["mirror_at_45_degrees"] = (Scene(1, 1, [Mesh([tri(*slanted, normal=(-r2, 0, -r2))], material=MIRROR, ior=1.5)],
                                        spheres=[((-6, 0, 5), 1.0, DIFFUSE, 1.3, (0.8, 0.4, 0.2))], lights=[((-2, 0, 5), (1, 1, 1), 5.0)], max_depth=1),
                                  tuple(kr45 * 5 / 3 * c for c in (0.8, 0.4, 0.2)), (0, 0, 1, 2))
+    # glass at oblique incidence (tracer.cu:102-115): the view direction turned about y to (0.6, 0, 0.8) meets the pane z = 5 in
+    # P = (3.75, 0, 5) with cos_i = 0.8; Snell into n = 1.5: sin_t = 0.4, the refracted direction T = (0.4, 0, sqrt 0.84).  A
+    # sphere of radius 0.5 sits 6 along T, a light 3 along T: the sphere's near point is 2.5 from the light along its
+    # normal, radiance 5 / 2.5 * colour.  The "reflected" ray of a glass surface is the NORMAL reflected about the view
+    # direction (tracer.cu:119): (0, 0, -1) - 2 (-0.8) (0.6, 0, 0.8) = (0.96, 0, 0.28), which starts a bias in front of the pane,
+    # meets the pane again at once, and at depth 2 > maxDepth both of that hit's children are the background.  Fresnel for
+    # cos_i = 0.8, cos_t = sqrt 0.84 (tracer.cu:67-89): pixel = kr * background + (1 - kr) * 2 * colour
+    ci, ct = 0.8, 0.84 ** 0.5
+    rs, rp = (1.5 * ci - ct) / (1.5 * ci + ct), (ci - 1.5 * ct) / (ci + 1.5 * ct)
+    kr = (rs * rs + rp * rp) / 2
+    rot = [[0.8, 0, -0.6, 0], [0, 1, 0, 0], [0.6, 0, 0.8, 0], [0, 0, 0, 1]]  # row-vector convention: (0, 0, 1) -> (0.6, 0, 0.8)
+    hit, T = np.array([3.75, 0.0, 5.0]), np.array([0.4, 0.0, ct])
+    colour = (0.1, 0.2, 0.3)
+    P["refract_oblique_incidence_follows_snell"] = (
+        Scene(1, 1, [Mesh([tri(*big)], material=GLASS, ior=1.5)], spheres=[(tuple(hit + 6 * T), 0.5, DIFFUSE, 1.3, colour)],
+              lights=[(tuple(hit + 3 * T), (1, 1, 1), 5.0)], max_depth=1, camera=rot),
+        tuple(kr * b + (1 - kr) * 2 * c for b, c in zip(BG, colour)), (0, 0, 1, 2))
     return P
+
+
+def camera_scene():
+    """Pixel -> primary ray (cudaTracer/Main.cu:42-60): a 4 x 2 frame with aspect ratio 2 and scale 1 sends the ray of pixel
+    (x, y) through ((2 (x + 0.5) / 4 - 1) * 2, 1 - 2 (y + 0.5) / 2, 1): the top-right pixel (3, 0) looks along (1.5, 0.5, 1).
+    A sphere of radius 0.1 at (6, 2, 4) lies on that ray and on no other (the neighbours pass (2, 2, 4) and (6, -2, 4)).
+    Light at the camera: the pixel is 5 / t * colour with t = |(6, 2, 4)| - 0.1.
+    Returns (scene, (x, y) of the one pixel that sees the sphere, its rgb)."""
+    colour = (0.8, 0.4, 0.2)
+    t = 56.0 ** 0.5 - 0.1
+    return Scene(4, 2, spheres=[((6, 2, 4), 0.1, DIFFUSE, 1.3, colour)], lights=LIGHT_AT_CAMERA), (3, 0), tuple(5 / t * c for c in colour)
 
 
 def bilinear_scene(u, v, mode=1):

@@ -15,7 +15,7 @@ def test_one_ray_scenes(gpu_ctx, name):
     if key is not None:
         assert tuple(keys[0, 0]) == key, (name, keys[0, 0])
     if rgb is not None:
-        assert np.allclose(rgba[0, 0, :3], rgb, rtol=2e-6, atol=1e-7), (name, rgba[0, 0])
+        assert np.allclose(rgba[0, 0, :3], rgb, rtol=hs.RTOL.get(name, 2e-6), atol=1e-7), (name, rgba[0, 0])
     assert rgba[0, 0, 3] == 1.0
 
 
@@ -23,6 +23,15 @@ def test_one_ray_scenes(gpu_ctx, name):
 def test_bilinear_filter(gpu_ctx, uvm, want):
     rgba, _ = hs.bilinear_scene(*uvm).render_gpu(gpu_ctx)
     assert np.allclose(rgba[0, 0, :3], want, atol=2e-6), (uvm, rgba[0, 0])
+
+
+def test_pixel_to_ray_mapping(gpu_ctx):
+    scene, (x, y), rgb = hs.camera_scene()
+    rgba, keys = scene.render_gpu(gpu_ctx)
+    seen = keys[:, :, 0] >= 0
+    assert seen[y, x] and seen.sum() == 1, keys[:, :, 0]
+    assert np.allclose(rgba[y, x, :3], rgb, rtol=1e-5), rgba[y, x]
+    assert np.allclose(rgba[~seen][:, :3], hs.BG, atol=1e-7)
 
 
 def test_near_far_order_flips_with_the_ray_sign(gpu_ctx):
