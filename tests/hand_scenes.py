@@ -279,6 +279,30 @@ def probes():
     P["mirror_at_45_degrees"] = (Scene(1, 1, [Mesh([tri(*slanted, normal=(-r2, 0, -r2))], material=MIRROR, ior=1.5)],
                                        spheres=[((-6, 0, 5), 1.0, DIFFUSE, 1.3, (0.8, 0.4, 0.2))], lights=[((-2, 0, 5), (1, 1, 1), 5.0)], max_depth=1),
                                  tuple(kr45 * 5 / 3 * c for c in (0.8, 0.4, 0.2)), (0, 0, 1, 2))
+    # Barycentric weights (cudaTracer/Mesh.cuh:33-57, 182-212): with v0 = (-1, -2, 5), e1 = (0, 4, 0), e2 = (4, 0, 0) the ray hits
+    # v0 + 0.5 e1 + 0.25 e2, so u = 0.5 belongs to vertex 1, v = 0.25 to vertex 2 and 0.25 to vertex 0.  Texture coordinates
+    # (0, 0), (1, 0.5), (0.5, 0.5) give st = (0.625, 0.375), the centre of texel x = 2, y = 1 of a 4 x 4 map (with u and v
+    # exchanged: (0.5, 0.375), between two texels).
+    skew = ((-1, -2, 5), (-1, 2, 5), (3, -2, 5))
+    px = [[(10 * x + 60 * y + 5, 255 - 50 * x, 40 * y) for x in range(4)] for y in range(4)]
+    P["texcoords_follow_the_barycentric_weights"] = (Scene(1, 1, [Mesh([tri(*skew, uv=((0, 0), (1, 0.5), (0.5, 0.5)))], diffuse=px)],
+                                                           lights=LIGHT_AT_CAMERA), tuple(c / 255 for c in px[1][2]), (0, 0, 1, 2))
+    # the same triangle with vertex normals (0, 0.8, -0.6), (0.6, 0, -0.8), (0, 0, -1): n = 0.25 n0 + 0.5 n1 + 0.25 n2 =
+    # (0.3, 0.2, -0.8), normalised; light at the camera: lambert = 0.8 / sqrt 0.77 (with u and v exchanged: 0.85 / sqrt 0.785)
+    corners = tri(*skew)
+    for c, n in zip(corners, ((0, 0.8, -0.6), (0.6, 0, -0.8), (0, 0, -1))):
+        c["normal"] = n
+    P["vertex_normals_follow_the_barycentric_weights"] = (Scene(1, 1, [Mesh([corners])], lights=LIGHT_AT_CAMERA), (0.8 / 0.77 ** 0.5,) * 3, (0, 0, 1, 2))
+    # Shadow rays against spheres (cudaTracer/Sphere.cuh:9-54 with the shadow ray's reach, tracer.cu:202-214): surface point
+    # (0, 0, 5), light at (3, 0, 1), 5 away along (0.6, 0, -0.8): lambert 0.8, light component 5 / 5.  A sphere of radius 0.5
+    # half way, at (1.5, 0, 3), blocks it (the primary ray passes 1.5 from its centre): black.  The same sphere beside the
+    # segment, or on the line but 7.5 from the surface (beyond the light): pixel = 0.8.
+    side_light = [((3, 0, 1), (1, 1, 1), 5.0)]
+    ball = lambda c: [(c, 0.5, DIFFUSE, 1.3, (1.0, 1.0, 1.0))]  # noqa: E731
+    P["sphere_between_surface_and_light_shadows"] = (Scene(1, 1, [Mesh([tri(*FRONT)])], spheres=ball((1.5, 0, 3)), lights=side_light),
+                                                     (0.0, 0.0, 0.0), (0, 0, 1, 2))
+    P["sphere_beside_the_shadow_ray"] = (Scene(1, 1, [Mesh([tri(*FRONT)])], spheres=ball((1.5, 2, 3)), lights=side_light), (0.8, 0.8, 0.8), (0, 0, 1, 2))
+    P["sphere_beyond_the_light"] = (Scene(1, 1, [Mesh([tri(*FRONT)])], spheres=ball((4.5, 0, -1)), lights=side_light), (0.8, 0.8, 0.8), (0, 0, 1, 2))
     # glass at oblique incidence (tracer.cu:102-115): the view direction turned about y to (0.6, 0, 0.8) meets the pane z = 5 in
     # P = (3.75, 0, 5) with cos_i = 0.8; Snell into n = 1.5: sin_t = 0.4, the refracted direction T = (0.4, 0, sqrt 0.84).  A
     # sphere of radius 0.5 sits 6 along T, a light 3 along T: the sphere's near point is 2.5 from the light along its
