@@ -279,7 +279,7 @@ def probes():
     P["mirror_at_45_degrees"] = (Scene(1, 1, [Mesh([tri(*slanted, normal=(-r2, 0, -r2))], material=MIRROR, ior=1.5)],
                                        spheres=[((-6, 0, 5), 1.0, DIFFUSE, 1.3, (0.8, 0.4, 0.2))], lights=[((-2, 0, 5), (1, 1, 1), 5.0)], max_depth=1),
                                  tuple(kr45 * 5 / 3 * c for c in (0.8, 0.4, 0.2)), (0, 0, 1, 2))
-    # Barycentric weights (cudaTracer/Mesh.cuh:33-57, 182-212): with v0 = (-1, -2, 5), e1 = (0, 4, 0), e2 = (4, 0, 0) the ray hits
+    # Barycentric weights (cudaTracer/Mesh.cuh:50-56, 101-109, 182-212): with v0 = (-1, -2, 5), e1 = (0, 4, 0), e2 = (4, 0, 0) the ray hits
     # v0 + 0.5 e1 + 0.25 e2, so u = 0.5 belongs to vertex 1, v = 0.25 to vertex 2 and 0.25 to vertex 0.  Texture coordinates
     # (0, 0), (1, 0.5), (0.5, 0.5) give st = (0.625, 0.375), the centre of texel x = 2, y = 1 of a 4 x 4 map (with u and v
     # exchanged: (0.5, 0.375), between two texels).
@@ -293,7 +293,7 @@ def probes():
     for c, n in zip(corners, ((0, 0.8, -0.6), (0.6, 0, -0.8), (0, 0, -1))):
         c["normal"] = n
     P["vertex_normals_follow_the_barycentric_weights"] = (Scene(1, 1, [Mesh([corners])], lights=LIGHT_AT_CAMERA), (0.8 / 0.77 ** 0.5,) * 3, (0, 0, 1, 2))
-    # Shadow rays against spheres (cudaTracer/Sphere.cuh:9-54 with the shadow ray's reach, tracer.cu:202-214): surface point
+    # Shadow rays against spheres (cudaTracer/Sphere.cuh:9-54 with the shadow ray's reach, tracer.cu:176-184): surface point
     # (0, 0, 5), light at (3, 0, 1), 5 away along (0.6, 0, -0.8): lambert 0.8, light component 5 / 5.  A sphere of radius 0.5
     # half way, at (1.5, 0, 3), blocks it (the primary ray passes 1.5 from its centre): black.  The same sphere beside the
     # segment, or on the line but 7.5 from the surface (beyond the light): pixel = 0.8.
@@ -324,7 +324,7 @@ def probes():
 
 
 def camera_scene():
-    """Pixel -> primary ray (cudaTracer/Main.cu:42-60): a 4 x 2 frame with aspect ratio 2 and scale 1 sends the ray of pixel
+    """Pixel -> primary ray (cudaTracer/Main.cu:57-76): a 4 x 2 frame with aspect ratio 2 and scale 1 sends the ray of pixel
     (x, y) through ((2 (x + 0.5) / 4 - 1) * 2, 1 - 2 (y + 0.5) / 2, 1): the top-right pixel (3, 0) looks along (1.5, 0.5, 1).
     A sphere of radius 0.1 at (6, 2, 4) lies on that ray and on no other (the neighbours pass (2, 2, 4) and (6, -2, 4)).
     Light at the camera: the pixel is 5 / t * colour with t = |(6, 2, 4)| - 0.1.
