@@ -314,6 +314,11 @@ constexpr unsigned char VIS_DEFERRED = 2;          // P.vis[] of such a shadow r
 #define RT_TRI_PART 16  // rays whose leaves are tested in one cooperative triangle phase (8 lanes each, 8 rays per round)
 #endif
 constexpr int kTriPart = RT_TRI_PART;
+#ifndef RT_TRI_GROUP
+#define RT_TRI_GROUP 8  // lanes that test one ray's leaf side by side (one triangle each)
+#endif
+constexpr int kGrp = RT_TRI_GROUP, kPerRound = 64 / kGrp, kRounds = kTriPart / kPerRound;
+static_assert((kGrp == 8 || kGrp == 4) && kTriPart % kPerRound == 0 && kRounds >= 1, "triangle phase geometry");
 static_assert(RT_MESH_ENTRY_SLOTS >= 6, "the mesh-entry save area holds six entries");
 constexpr size_t kTriLdsBytes = (size_t)kTriPart * (2 * sizeof(float4) + 8 * sizeof(float) + 8 * sizeof(float2));
 
@@ -646,14 +651,14 @@ __global__ void __launch_bounds__(kWave, ANY ? RT_MIN_WAVES_ANY : RT_MIN_WAVES) 
                 }
                 __syncthreads();
                 STAMP(4);  // triangle phase: rays published
-                const int rounds = (nPart + 7) >> 3;
+                const int rounds = (nPart + kPerRound - 1) / kPerRound;
                 // ANY: lanes whose triangle the ray accepts, per round (bit = lane: 8 bits per participating ray)
-                unsigned long long accepted[kTriPart / 8] = {};
+                unsigned long long accepted[kRounds] = {};
 #pragma unroll
-                for (int r = 0; r < kTriPart / 8; ++r) {
+                for (int r = 0; r < kRounds; ++r) {
                     if (r >= rounds) break;
-                    const int rr = r * 8 + (lane >> 3);
-                    const unsigned k = (unsigned)lane & 7u;
+                    const int rr = r * kPerRound + lane / kGrp;
+                    const unsigned k = (unsigned)lane % (unsigned)kGrp;
                     const float4 A = rayBuf[2 * rr], B = rayBuf[2 * rr + 1];
                     const unsigned idx = __float_as_uint(A.w) + k;
                     float t = -1.0f, u = 0.0f, v = 0.0f;
@@ -689,8 +694,8 @@ __global__ void __launch_bounds__(kWave, ANY ? RT_MIN_WAVES_ANY : RT_MIN_WAVES) 
                         // the first accepted triangle of the leaf ends the walk (later ones cannot change the answer)
                         unsigned long long m = accepted[0];
 #pragma unroll
-                        for (int r = 1; r < kTriPart / 8; ++r) m = (rank >> 3) == (unsigned)r ? accepted[r] : m;
-                        const unsigned bits = (unsigned)(m >> ((rank & 7u) * 8u)) & 0xffu;
+                        for (int r = 1; r < kRounds; ++r) m = (rank / (unsigned)kPerRound) == (unsigned)r ? accepted[r] : m;
+                        const unsigned bits = (unsigned)(m >> ((rank % (unsigned)kPerRound) * (unsigned)kGrp)) & ((1u << kGrp) - 1u);
                         win = bits ? __ffs((int)bits) - 1 : -1;
                     } else {
                         // cudaTracer/Mesh.cuh:141-146 + 205-208: leaf triangles in order; a hit needs t >= 0 and t <= reach,
@@ -698,14 +703,14 @@ __global__ void __launch_bounds__(kWave, ANY ? RT_MIN_WAVES_ANY : RT_MIN_WAVES) 
                         const float4 ta = reinterpret_cast<const float4*>(tBuf)[2 * rank], tb = reinterpret_cast<const float4*>(tBuf)[2 * rank + 1];
                         const float ts[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
+                        for (int k = 0; k < kGrp; ++k) {
                             const bool acc = !(ts[k] < 0.0f) && !(tMax < ts[k]);
                             tMax = acc ? ts[k] : tMax;
                             win = acc ? k : win;
                         }
                     }
                     const unsigned left = end - next;
-                    if (COUNT) cTri += (ANY && win >= 0) ? (unsigned)win + 1u : (left < 8u ? left : 8u);
+                    if (COUNT) cTri += (ANY && win >= 0) ? (unsigned)win + 1u : (left < (unsigned)kGrp ? left : (unsigned)kGrp);
                     if (win >= 0) {
                         if (!ANY) {
                             const float2 uv = uvBuf[rank * 8 + win];
@@ -715,7 +720,7 @@ __global__ void __launch_bounds__(kWave, ANY ? RT_MIN_WAVES_ANY : RT_MIN_WAVES) 
                         }
                         hShape = HIT_PENDING;
                     }
-                    const unsigned nn = next + 8u;
+                    const unsigned nn = next + (unsigned)kGrp;
                     cur = (ANY && win >= 0) ? CUR_DONE : (nn >= end ? CUR_POP : (TAG_TRI | nn));
                 }
                 STAMP(7);  // triangle phase: results applied
