@@ -502,6 +502,8 @@ def main():
             ("cfg 2 handed over with the reference's own BVH, mesh BVHs built again on the device at upload (rt_set_upload_rebuild): the "
              "reference's median cut on true bounds, same image; what a host that passes the reference's arrays gets with one switch",
              ("soup", w, h, args.size, args.lights, args.max_depth), {"tight_bvh": False, "upload_rebuild": True}),
+            ("cfg 2 with 10 lights (the workload's second run): the headline's soup and surface-area tree, ten shadow rays per hit",
+             ("soup", w, h, args.size, 10, args.max_depth), {"tight_bvh": True, "sah_bvh": True}),
             ("cfg 1: 16x16 grid of cube meshes (one mesh BVH each) under a scene BVH, 640x480, 4 lights, maxDepth 5",
              ("cubes", 640, 480, 16, 4, 5), {"tight_bvh": True}),
             ("cfg 3: OBJ barrel (488 triangles, three 1024x1024 maps) in three instances, one a mirror, textured plane, mirror and "
