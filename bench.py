@@ -187,10 +187,13 @@ def time_frames(ctx, render, frames, in_flight, surfaces):
 def other_workload(ctx, torch, dev, label, scene_args, scene_kwargs, nf):
     """In-order and in-flight figures of another workload of the scope table, on the same kernels.
     scene_kwargs["upload_refit"]: upload with rt_set_upload_refit on (boxes recomputed on the device);
-    scene_kwargs["upload_rebuild"]: with rt_set_upload_rebuild on (mesh BVHs built again on the device)."""
+    scene_kwargs["upload_rebuild"]: with rt_set_upload_rebuild on (mesh BVHs built again on the device);
+    scene_kwargs["unlit_skip"]: timed with rt_set_unlit_shadow_skip on - the row then states frame times only, because
+    fewer rays are walked than the counters (which follow the reference) say."""
     scene_kwargs = dict(scene_kwargs)
     refit = scene_kwargs.pop("upload_refit", False)
     rebuild = scene_kwargs.pop("upload_rebuild", False)
+    unlit_skip = scene_kwargs.pop("unlit_skip", False)
     t0 = time.perf_counter()
     scene = rt.HostScene(*scene_args, **scene_kwargs)
     build_s = time.perf_counter() - t0
@@ -215,18 +218,27 @@ def other_workload(ctx, torch, dev, label, scene_args, scene_kwargs, nf):
     def render(s):
         ctx.render(dscene, opts, cam, s.data_ptr(), pitch)
 
-    wall1, ev1 = time_frames(ctx, render, 10, 1, surfaces)
-    walln, _ = time_frames(ctx, render, 6 * nf, nf, surfaces)  # long enough that filling and draining the slots does not show
+    ctx.set_unlit_shadow_skip(unlit_skip)
+    try:
+        wall1, ev1 = time_frames(ctx, render, 10, 1, surfaces)
+        walln, _ = time_frames(ctx, render, 6 * nf, nf, surfaces)  # long enough that filling and draining the slots does not show
+    finally:
+        ctx.set_unlit_shadow_skip(False)
     ctx.set_frames_in_flight(1)
     ctx.free_scene(dscene)
     scene.close()
     del surfaces
     torch.cuda.empty_cache()
-    return {"workload": label, "rays_per_frame": rays, "primary": cnt["primary"], "shadow": cnt["shadow"], "secondary": cnt["secondary"],
-            "box_tests_per_ray": cnt["node"] / max(rays, 1), "triangle_tests_per_ray": cnt["tri"] / max(rays, 1),
-            "in_order_ms_per_frame": ev1[0], "in_order_Mrays_per_s": rays / wall1 / 1e3,
-            "in_flight_ms_per_frame": walln, "in_flight_Mrays_per_s": rays / walln / 1e3, "frames_in_flight": nf,
-            "scene_build_s": round(build_s, 2), "upload_s": round(upload_s, 2)}
+    row = {"workload": label, "rays_per_frame": rays, "primary": cnt["primary"], "shadow": cnt["shadow"], "secondary": cnt["secondary"],
+           "box_tests_per_ray": cnt["node"] / max(rays, 1), "triangle_tests_per_ray": cnt["tri"] / max(rays, 1),
+           "in_order_ms_per_frame": ev1[0], "in_order_Mrays_per_s": rays / wall1 / 1e3,
+           "in_flight_ms_per_frame": walln, "in_flight_Mrays_per_s": rays / walln / 1e3, "frames_in_flight": nf,
+           "scene_build_s": round(build_s, 2), "upload_s": round(upload_s, 2)}
+    if unlit_skip:
+        row["in_order_Mrays_per_s"] = row["in_flight_Mrays_per_s"] = None
+        row["note"] = ("rays_per_frame and the tests per ray are the reference's (counter frames walk every ray); the timed frames leave out the shadow "
+                       "rays of lights behind the surface, so only the frame times compare with the row without the switch")
+    return row
 
 
 def default_queue_run(args, nf):
@@ -504,6 +516,9 @@ def main():
              ("soup", w, h, args.size, args.lights, args.max_depth), {"tight_bvh": False, "upload_rebuild": True}),
             ("cfg 2 with 10 lights (the workload's second run): the headline's soup and surface-area tree, ten shadow rays per hit",
              ("soup", w, h, args.size, 10, args.max_depth), {"tight_bvh": True, "sah_bvh": True}),
+            ("cfg 2 with 10 lights and rt_set_unlit_shadow_skip: shadow rays towards lights behind the surface (lambert 0, nothing to add) are "
+             "not walked; same pixels",
+             ("soup", w, h, args.size, 10, args.max_depth), {"tight_bvh": True, "sah_bvh": True, "unlit_skip": True}),
             ("cfg 1: 16x16 grid of cube meshes (one mesh BVH each) under a scene BVH, 640x480, 4 lights, maxDepth 5",
              ("cubes", 640, 480, 16, 4, 5), {"tight_bvh": True}),
             ("cfg 3: OBJ barrel (488 triangles, three 1024x1024 maps) in three instances, one a mirror, textured plane, mirror and "

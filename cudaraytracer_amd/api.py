@@ -368,6 +368,10 @@ class Context:
         """Level-0 traces of at least this many primary rays run as two launches (min / max box test, then the literal one)."""
         self._check(self.lib.rt_set_box_test_split(self.ctx, min_rays), "rt_set_box_test_split")
 
+    def set_unlit_shadow_skip(self, on=True):
+        """rt_set_unlit_shadow_skip: shadow rays towards lights behind the surface (lambert == 0) are not walked; same pixels."""
+        self._check(self.lib.rt_set_unlit_shadow_skip(self.ctx, 1 if on else 0), "rt_set_unlit_shadow_skip")
+
     def set_lds_stack(self, entries):
         self._check(self.lib.rt_set_lds_stack(self.ctx, entries), "rt_set_lds_stack")
 

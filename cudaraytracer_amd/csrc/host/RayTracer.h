@@ -42,6 +42,9 @@ class RayTracer {
     // bounds instead of the reference's FLT_MIN-clamped ones - several times fewer tests per ray than the refit alone
     // leaves, at the price of the reference's order among equal-distance hits.
     bool rebuildAtUpload = false;
+    // Shadow rays towards lights behind the surface are not walked (rt_set_unlit_shadow_skip): the reference adds zeros for
+    // them whatever they find (tracer.cu:181-196), so the image is the same bit for bit and the shadow launch is shorter.
+    bool skipUnlitShadowRays = false;
 
     explicit RayTracer(Options options, BVH::BoundsMode bounds = BVH::REFERENCE_BOUNDS) : options(options), boundsMode(bounds) {}
     RayTracer(const RayTracer&) = delete;
@@ -174,6 +177,7 @@ class RayTracer {
         const RtSceneDesc desc = currentScene().describe(shapeStore, meshStore);
         check(rt_set_upload_refit(ctx, refitAtUpload ? 1 : 0), "rt_set_upload_refit");
         check(rt_set_upload_rebuild(ctx, rebuildAtUpload ? 1 : 0), "rt_set_upload_rebuild");
+        check(rt_set_unlit_shadow_skip(ctx, skipUnlitShadowRays ? 1 : 0), "rt_set_unlit_shadow_skip");
         devScene = rt_scene_upload(ctx, &desc);
         if (!devScene) throw std::runtime_error(std::string("rt_scene_upload: ") + rt_last_error(ctx));
         check(rt_surface_create(ctx, options.device.width, options.device.height, &surface, &pitch), "rt_surface_create");
@@ -191,6 +195,8 @@ class RayTracer {
         const RtSceneDesc desc = currentScene().describe(shapeStore, meshStore);
         check(rt_set_upload_refit(ctx, refitAtUpload ? 1 : 0), "rt_set_upload_refit");
         check(rt_set_upload_rebuild(ctx, rebuildAtUpload ? 1 : 0), "rt_set_upload_rebuild");
+        for (int i = 0; i < rt_multi_device_count(node); ++i)  // a render-time switch of each device's own context
+            check(rt_set_unlit_shadow_skip(rt_multi_context(node, i), skipUnlitShadowRays ? 1 : 0), "rt_set_unlit_shadow_skip");
         checkMulti(rt_multi_scene_upload(multi, &desc), "rt_multi_scene_upload");
         check(rt_surface_create(ctx, options.device.width, options.device.height, &surface, &pitch), "rt_surface_create");
         if (balanceTiles) {

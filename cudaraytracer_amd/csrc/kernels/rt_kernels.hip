@@ -277,7 +277,10 @@ __device__ __forceinline__ void nodeRay(const FrameParams& P, int node, V3& o, V
 // Shadow ray of (diffuse hit k, light i), cudaTracer/tracer.cu:175-183: origin
 // biased along the normal by the sign of view . n, direction and reach taken
 // from the UNBIASED hit point.
-__device__ __forceinline__ void shadowRay(const FrameParams& P, unsigned k, int light, V3& o, V3& d, float& tMax) {
+// `unlit`: the light cannot contribute whatever the ray finds - lambert (tracer.cu:181, formed as accumKernel forms it)
+// is 0, and lightComponent (tracer.cu:194) is certainly finite, so that its products with lambert and with the specular
+// factor, which is 0 with lambert, are zeros.
+__device__ __forceinline__ void shadowRay(const FrameParams& P, unsigned k, int light, V3& o, V3& d, float& tMax, bool& unlit) {
     const float4* c = P.ctx + 4 * (size_t)k;
     const float4 c0 = c[0], c1 = c[1], c2 = c[2];
     const V3 hitPoint = mk(c0.x, c0.y, c0.z);
@@ -288,6 +291,9 @@ __device__ __forceinline__ void shadowRay(const FrameParams& P, unsigned k, int 
     tMax = magnitude(lightDir);
     d = normalized(lightDir);
     o = biasedOrigin(view, hitPoint, n, P.opts.shadowBias);
+    const V3 scaled = muls(mk(L->intensity), L->power);
+    const float big = 1e18f;
+    unlit = !(dot(d, n) > 0.0f) && tMax > 1e-20f && __builtin_fabsf(scaled.x) < big && __builtin_fabsf(scaled.y) < big && __builtin_fabsf(scaled.z) < big;
 }
 
 // What a lane does next is held in ONE word, `cur`:
@@ -569,7 +575,12 @@ __global__ void __launch_bounds__(kWave, ANY ? RT_MIN_WAVES_ANY : RT_MIN_WAVES) 
                 } else if (ANY) {
                     const unsigned k = (unsigned)item / (unsigned)P.lightCnt;
                     const int li = (int)((unsigned)item - k * (unsigned)P.lightCnt);
-                    shadowRay(P, k, li, o, d, tMax);
+                    bool unlit;
+                    shadowRay(P, k, li, o, d, tMax, unlit);
+                    if (!COUNT && P.skipUnlit != 0 && !rescue && unlit) {
+                        P.vis[item] = 0;  // "hidden": accumKernel passes over the light, which is what adding its zeros comes to
+                        item = -1;
+                    }
                 } else {
                     if (item < P.slots) {
                         int x, y;
@@ -615,6 +626,8 @@ __global__ void __launch_bounds__(kWave, ANY ? RT_MIN_WAVES_ANY : RT_MIN_WAVES) 
             if (exhausted) break;
             continue;
         }
+        // rays that were not started (lights that cannot contribute) leave their lanes free: fill up again before walking
+        if (ANY && !COUNT && P.skipUnlit != 0 && !exhausted && pop64(__ballot(item < 0)) >= RT_REFILL_LANES / 2) continue;
 
         STAMP(0);  // refill
         // ---- advance the rays until enough lanes have finished --------------

@@ -89,6 +89,7 @@ struct rt_ctx {
     unsigned long long frameCounter = 0;  // frames issued so far
     int pathBudget = 3;  // node arrays hold pathBudget x pixels when the scene has mirror / glass materials
     int splitSlots = 100000;              // rt_set_box_test_split
+    bool skipUnlit = false;               // rt_set_unlit_shadow_skip
     int ldsStack = RT_LDS_STACK_DEFAULT;  // traversal stack entries kept in LDS (older ones move to global memory)
     int maxWavesPerCu = 0;                // 0 = as many as are resident
     uint32_t sampleSeed = 1234;
@@ -872,6 +873,12 @@ int rt_set_box_test_split(rt_ctx* ctx, int minRays) {
     return RT_OK;
 }
 
+int rt_set_unlit_shadow_skip(rt_ctx* ctx, int on) {
+    if (!ctx) return RT_ERR_INVALID;
+    ctx->skipUnlit = on != 0;
+    return RT_OK;
+}
+
 int rt_set_workspace_guards(rt_ctx* ctx, size_t bytes) {
     if (!ctx) return RT_ERR_INVALID;
     if (bytes > (1u << 20) || bytes % 256 != 0) return fail(ctx, RT_ERR_INVALID, "guard size must be a multiple of 256 bytes, at most 1 MiB");
@@ -1381,6 +1388,7 @@ int renderFrame(rt_ctx* ctx, rt_scene* scene, const RtDeviceOpts* opts, const Rt
     p.waveChunks = 4;
     p.waveChunksLarge = ctx->framesInFlight > 1 ? 6 : 4;  // alone on the machine, a launch is shortest with the most wavefronts
     p.splitSlots = ctx->splitSlots;
+    p.skipUnlit = ctx->skipUnlit ? 1 : 0;
     p.tileFirst = tileFirst;
     p.tileStride = tileStride;
     p.tileCnt = (int)myTiles;

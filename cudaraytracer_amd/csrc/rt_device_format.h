@@ -218,6 +218,7 @@ struct FrameParams {
     int32_t waveChunks;                      // 64-ray chunks a wavefront should get at least before another one joins in
     int32_t waveChunksLarge;                 // the same for launches of 6000 chunks and more
     int32_t splitSlots;                      // level-0 traces of at least this many rays run as two launches (min / max box test + literal)
+    int32_t skipUnlit;                       // shadow rays towards lights that cannot contribute are not walked (rt_set_unlit_shadow_skip)
     // workspace (device pointers)
     uint32_t* ctl;          // CTL_WORDS
     float4* hit;            // [nodeCap] {t, u, v, shape slot as int bits (-1 miss, -2 outside the frame)}

@@ -458,6 +458,17 @@ int rt_set_lds_stack(rt_ctx* ctx, int entries);
  * in one launch: with many such frames in flight the extra launches cost more than the shorter walk saves.  Results do not depend on it, bit for bit.  No counterpart in the reference. */
 int rt_set_box_test_split(rt_ctx* ctx, int minRays);
 
+/* Shadow rays that cannot matter.  The reference walks one shadow ray per diffuse hit and light
+ * (cudaTracer/tracer.cu:176-184) and then adds lightComponent * lambert and lightComponent * specMask * specularFac,
+ * where specularFac is 0 unless lambert > 0 (tracer.cu:186-196): for a light behind the surface (lambert == 0) both
+ * terms are zeros whatever the ray finds, and adding them changes nothing.  With `on` != 0 such a ray is not walked
+ * (its light counts as hidden); it is walked as always when the zero is not certain - a light within 1e-20 of the
+ * surface point or an intensity * power beyond 1e18, where the reference's term could be a NaN or an infinity.  Pixels,
+ * hit keys and counters are the same bit for bit (counter frames walk every ray, as the reference does); what changes is the
+ * time of the shadow launch and the number of rays actually walked, which is below primary + shadow of the counters.
+ * Off by default, so that rays per second means rays walked.  No counterpart in the reference. */
+int rt_set_unlit_shadow_skip(rt_ctx* ctx, int on);
+
 /* Frames in flight (1..16, default 1).  With 1, rt_render enqueues the frame on the
  * context's stream, in order, as the reference's cudamain does on the default
  * stream (cudaTracer/Main.cu:92-119).  With more, consecutive rt_render calls run

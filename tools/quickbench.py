@@ -25,6 +25,7 @@ ap.add_argument("--reference-bvh", action="store_true")
 ap.add_argument("--lds-stack", type=int, default=0)
 ap.add_argument("--frames-in-flight", type=int, default=0)
 ap.add_argument("--waves", type=int, default=0)
+ap.add_argument("--skip-unlit", action="store_true", help="rt_set_unlit_shadow_skip: shadow rays towards lights behind the surface are not walked")
 ap.add_argument("--split", type=int, default=-1, help="rt_set_box_test_split: level-0 traces of at least this many rays run as two launches")
 ap.add_argument("--cost-order", action="store_true", help="tiles in order of falling cost, measured by a counter frame (rt_set_tile_list)")
 ap.add_argument("--tile-order", type=int, default=-1)
@@ -54,6 +55,8 @@ with rt.Context(0) as ctx:
         ctx.set_trace_waves(a.waves)
     if a.split >= 0:
         ctx.set_box_test_split(a.split)
+    if a.skip_unlit:
+        ctx.set_unlit_shadow_skip(True)
     if a.tile_order >= 0:
         ctx.set_tile_order(a.tile_order)
     if a.frames_in_flight:
