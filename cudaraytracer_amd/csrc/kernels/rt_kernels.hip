@@ -291,9 +291,14 @@ __device__ __forceinline__ void shadowRay(const FrameParams& P, unsigned k, int 
     tMax = magnitude(lightDir);
     d = normalized(lightDir);
     o = biasedOrigin(view, hitPoint, n, P.opts.shadowBias);
-    const V3 scaled = muls(mk(L->intensity), L->power);
-    const float big = 1e18f;
-    unlit = !(dot(d, n) > 0.0f) && tMax > 1e-20f && __builtin_fabsf(scaled.x) < big && __builtin_fabsf(scaled.y) < big && __builtin_fabsf(scaled.z) < big;
+    unlit = false;
+    if (P.skipUnlit != 0 && !(dot(d, n) > 0.0f)) {
+        // lightComponent = intensity * power / distance below 1e38 in size, and its product with the specular mask too
+        const V3 scaled = muls(mk(L->intensity), L->power);
+        const float big = 1e18f, specMask = c[3].x;
+        unlit = tMax > 1e-20f && __builtin_fabsf(scaled.x) < big && __builtin_fabsf(scaled.y) < big && __builtin_fabsf(scaled.z) < big &&
+                __builtin_fabsf(specMask) <= 1.0f;
+    }
 }
 
 // What a lane does next is held in ONE word, `cur`:
@@ -577,7 +582,7 @@ __global__ void __launch_bounds__(kWave, ANY ? RT_MIN_WAVES_ANY : RT_MIN_WAVES) 
                     const int li = (int)((unsigned)item - k * (unsigned)P.lightCnt);
                     bool unlit;
                     shadowRay(P, k, li, o, d, tMax, unlit);
-                    if (!COUNT && P.skipUnlit != 0 && !rescue && unlit) {
+                    if (!COUNT && !rescue && unlit) {
                         P.vis[item] = 0;  // "hidden": accumKernel passes over the light, which is what adding its zeros comes to
                         item = -1;
                     }

@@ -463,7 +463,8 @@ int rt_set_box_test_split(rt_ctx* ctx, int minRays);
  * where specularFac is 0 unless lambert > 0 (tracer.cu:186-196): for a light behind the surface (lambert == 0) both
  * terms are zeros whatever the ray finds, and adding them changes nothing.  With `on` != 0 such a ray is not walked
  * (its light counts as hidden); it is walked as always when the zero is not certain - a light within 1e-20 of the
- * surface point or an intensity * power beyond 1e18, where the reference's term could be a NaN or an infinity.  Pixels,
+ * surface point, an intensity * power beyond 1e18 or a specular mask (a sphere's Ks) beyond 1, where the reference's
+ * term could be a NaN or an infinity.  Pixels,
  * hit keys and counters are the same bit for bit (counter frames walk every ray, as the reference does); what changes is the
  * time of the shadow launch and the number of rays actually walked, which is below primary + shadow of the counters.
  * Off by default, so that rays per second means rays walked.  No counterpart in the reference. */

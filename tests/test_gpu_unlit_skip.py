@@ -52,5 +52,14 @@ def test_light_behind_the_surface_and_the_cases_that_are_walked(gpu_ctx, oracle)
             rgba, keys = scene.render_gpu(gpu_ctx)
             assert np.array_equal(keys, ref_keys)
             assert np.array_equal(rgba, ref_rgba, equal_nan=True), (lights, rgba, ref_rgba)
+        # a sphere whose Ks is infinite, lit from behind and from the front: 0 * inf is a NaN the reference lets through
+        # only for a visible light
+        for lights in (behind, behind + hs.LIGHT_AT_CAMERA):
+            scene = hs.Scene(1, 1, spheres=[((0, 0, 5), 1.0, hs.DIFFUSE, 1.3, (0.4, 0.2, 0.1))], lights=lights)
+            scene.shapes[0].material.Ks = float("inf")
+            ref_rgba, ref_keys = scene.render_oracle(oracle)
+            rgba, keys = scene.render_gpu(gpu_ctx)
+            assert np.array_equal(keys, ref_keys)
+            assert np.array_equal(rgba, ref_rgba, equal_nan=True), (lights, rgba, ref_rgba)
     finally:
         gpu_ctx.set_unlit_shadow_skip(False)
