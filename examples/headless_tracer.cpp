@@ -79,6 +79,7 @@ void initScene(RayTracer& tracer, const Options& opts, const std::string& assets
 int main(int argc, char** argv) {
     std::string experimentFname, out = "frame.png", assets;
     int phaseIdx = 0, frames = 1, positional = 0;
+    bool skipUnlit = false;  // shadow rays towards lights behind the surface are not walked (same image)
     std::vector<int> devices{0};
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -88,6 +89,8 @@ int main(int argc, char** argv) {
             out = argv[++i];
         else if (a == "--assets" && i + 1 < argc)
             assets = argv[++i];
+        else if (a == "--skip-unlit")
+            skipUnlit = true;
         else if (a == "--gpus" && i + 1 < argc) {
             // a count ("4": devices 0..3) or a list ("0,0": the same GPU twice, two contexts)
             const std::string v = argv[++i];
@@ -111,7 +114,7 @@ int main(int argc, char** argv) {
             phaseIdx = std::atoi(a.c_str());
             positional++;
         } else {
-            std::fprintf(stderr, "usage: %s [experiment.json [phase]] [--frames N] [--out file.png] [--assets DIR] [--gpus N | --gpus d0,d1,...]\n", argv[0]);
+            std::fprintf(stderr, "usage: %s [experiment.json [phase]] [--frames N] [--out file.png] [--assets DIR] [--gpus N | --gpus d0,d1,...] [--skip-unlit]\n", argv[0]);
             return 2;
         }
     }
@@ -132,6 +135,7 @@ int main(int argc, char** argv) {
             label = reader.experiment.experimentName + " / " + phase.phaseName;
         }
         RayTracer tracer(options);
+        tracer.skipUnlitShadowRays = skipUnlit;
         initScene(tracer, options, assets);
 
         rt_ctx* ctx = nullptr;
