@@ -194,12 +194,16 @@ def other_workload(ctx, torch, dev, label, scene_args, scene_kwargs, nf):
     refit = scene_kwargs.pop("upload_refit", False)
     rebuild = scene_kwargs.pop("upload_rebuild", False)
     unlit_skip = scene_kwargs.pop("unlit_skip", False)
+    device_sah = scene_kwargs.pop("device_sah", 0)  # leaf threshold: the device cuts the meshes it builds by the binned surface-area heuristic
     t0 = time.perf_counter()
     scene = rt.HostScene(*scene_args, **scene_kwargs)
     build_s = time.perf_counter() - t0
     w, h = scene.width, scene.height
     ctx.set_upload_refit(refit)
     ctx.set_upload_rebuild(rebuild)
+    if device_sah:
+        ctx.set_device_bvh(device_sah, True)
+        ctx.set_device_bvh_rule(sah=True)
     t0 = time.perf_counter()
     try:
         dscene = ctx.upload(scene)
@@ -207,6 +211,8 @@ def other_workload(ctx, torch, dev, label, scene_args, scene_kwargs, nf):
     finally:
         ctx.set_upload_refit(False)
         ctx.set_upload_rebuild(False)
+        ctx.set_device_bvh_rule(sah=False)
+        ctx.set_device_bvh(10, True)
     upload_s = time.perf_counter() - t0
     surfaces = [torch.zeros((h, w, 4), dtype=torch.float32, device=dev) for _ in range(nf)]
     pitch = w * 16
@@ -514,6 +520,9 @@ def main():
             ("cfg 2 handed over with the reference's own BVH, mesh BVHs built again on the device at upload (rt_set_upload_rebuild): the "
              "reference's median cut on true bounds, same image; what a host that passes the reference's arrays gets with one switch",
              ("soup", w, h, args.size, args.lights, args.max_depth), {"tight_bvh": False, "upload_rebuild": True}),
+            ("cfg 2 handed over with the reference's own BVH, mesh BVHs cut again on the device by the binned surface-area heuristic "
+             "(rt_set_upload_rebuild + rt_set_device_bvh_rule, leaves of 8): the headline's tree, built in 0.06 s at upload",
+             ("soup", w, h, args.size, args.lights, args.max_depth), {"tight_bvh": False, "upload_rebuild": True, "device_sah": 8}),
             ("cfg 2 with 10 lights (the workload's second run): the headline's soup and surface-area tree, ten shadow rays per hit",
              ("soup", w, h, args.size, 10, args.max_depth), {"tight_bvh": True, "sah_bvh": True}),
             ("cfg 2 with 10 lights and rt_set_unlit_shadow_skip: shadow rays towards lights behind the surface (lambert 0, nothing to add) are "
@@ -526,6 +535,8 @@ def main():
              ("barrel", 1920, 1080, 0, 10, 2), {"asset_dir": assets, "tight_bvh": True}),
             ("cfg 4: height field of 9 999 392 triangles in one mesh BVH cut by the surface-area heuristic (host build), 3840x2160, 1 light",
              ("heightfield", 3840, 2160, 10000000, 1, 0), {"tight_bvh": True, "sah_bvh": True}),
+            ("cfg 4 with the same surface-area tree cut on the device (rt_set_device_bvh_rule; upload_s includes the build)",
+             ("heightfield", 3840, 2160, 10000000, 1, 0), {"tight_bvh": True, "device_bvh": True, "device_sah": 8}),
             ("cfg 4 with the reference's median-cut tree, built on the device (rt_set_device_bvh)",
              ("heightfield", 3840, 2160, 10000000, 1, 0), {"tight_bvh": True, "device_bvh": True}),
             ("cfg 5: default-scene analogue (sphere field, mirror and glass balls, textured plane, three mesh instances), "

@@ -111,6 +111,7 @@ C_ABI = {
     "rt_set_path_budget": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_lds_stack": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_box_test_split": (C.c_int, [C.c_void_p, C.c_int]),
+    "rt_set_device_bvh_rule": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_set_unlit_shadow_skip": (C.c_int, [C.c_void_p, C.c_int]),
     "rt_mesh_bvh_build": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.POINTER(C.c_int), C.c_void_p]),

@@ -368,6 +368,11 @@ class Context:
         """Level-0 traces of at least this many primary rays run as two launches (min / max box test, then the literal one)."""
         self._check(self.lib.rt_set_box_test_split(self.ctx, min_rays), "rt_set_box_test_split")
 
+    def set_device_bvh_rule(self, sah=False):
+        """rt_set_device_bvh_rule: meshes built on the device are cut at the median (the reference's rule) or by the binned
+        surface-area heuristic (the tree of the host builder with that rule, decided on the device)."""
+        self._check(self.lib.rt_set_device_bvh_rule(self.ctx, 1 if sah else 0), "rt_set_device_bvh_rule")
+
     def set_unlit_shadow_skip(self, on=True):
         """rt_set_unlit_shadow_skip: shadow rays towards lights behind the surface (lambert == 0) are not walked; same pixels."""
         self._check(self.lib.rt_set_unlit_shadow_skip(self.ctx, 1 if on else 0), "rt_set_unlit_shadow_skip")

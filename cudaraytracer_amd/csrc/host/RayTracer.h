@@ -42,6 +42,10 @@ class RayTracer {
     // bounds instead of the reference's FLT_MIN-clamped ones - several times fewer tests per ray than the refit alone
     // leaves, at the price of the reference's order among equal-distance hits.
     bool rebuildAtUpload = false;
+    // How the device cuts the mesh BVHs it builds - meshes without nodes, and all of them under rebuildAtUpload
+    // (rt_set_device_bvh_rule): at the median, as the reference does, or by the binned surface-area heuristic (needs the
+    // context's device builds on tight bounds, which is their default).
+    BVH::SplitRule deviceSplitRule = BVH::MEDIAN_CUT;
     // Shadow rays towards lights behind the surface are not walked (rt_set_unlit_shadow_skip): the reference adds zeros for
     // them whatever they find (tracer.cu:181-196), so the image is the same bit for bit and the shadow launch is shorter.
     bool skipUnlitShadowRays = false;
@@ -177,6 +181,7 @@ class RayTracer {
         const RtSceneDesc desc = currentScene().describe(shapeStore, meshStore);
         check(rt_set_upload_refit(ctx, refitAtUpload ? 1 : 0), "rt_set_upload_refit");
         check(rt_set_upload_rebuild(ctx, rebuildAtUpload ? 1 : 0), "rt_set_upload_rebuild");
+        check(rt_set_device_bvh_rule(ctx, deviceSplitRule == BVH::BINNED_SAH ? RT_BVH_BINNED_SAH : RT_BVH_MEDIAN_CUT), "rt_set_device_bvh_rule");
         check(rt_set_unlit_shadow_skip(ctx, skipUnlitShadowRays ? 1 : 0), "rt_set_unlit_shadow_skip");
         devScene = rt_scene_upload(ctx, &desc);
         if (!devScene) throw std::runtime_error(std::string("rt_scene_upload: ") + rt_last_error(ctx));
@@ -195,6 +200,7 @@ class RayTracer {
         const RtSceneDesc desc = currentScene().describe(shapeStore, meshStore);
         check(rt_set_upload_refit(ctx, refitAtUpload ? 1 : 0), "rt_set_upload_refit");
         check(rt_set_upload_rebuild(ctx, rebuildAtUpload ? 1 : 0), "rt_set_upload_rebuild");
+        check(rt_set_device_bvh_rule(ctx, deviceSplitRule == BVH::BINNED_SAH ? RT_BVH_BINNED_SAH : RT_BVH_MEDIAN_CUT), "rt_set_device_bvh_rule");
         for (int i = 0; i < rt_multi_device_count(node); ++i)  // a render-time switch of each device's own context
             check(rt_set_unlit_shadow_skip(rt_multi_context(node, i), skipUnlitShadowRays ? 1 : 0), "rt_set_unlit_shadow_skip");
         checkMulti(rt_multi_scene_upload(multi, &desc), "rt_multi_scene_upload");

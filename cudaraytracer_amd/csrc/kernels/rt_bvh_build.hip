@@ -492,6 +492,333 @@ int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* streamPtr) {
 }
 
 // ---------------------------------------------------------------------------
+// Surface-area cuts on the device (rt_set_device_bvh_rule, RT_BVH_BINNED_SAH): the tree of csrc/host/BVH.h's
+// sahPartition - every range cut where the heuristic over 32 centroid bins per axis is lowest - decided level by level
+// on the device.  The tree's shape depends on the data, so the HOST keeps it: per level it hands over the ranges that
+// are still to be cut (ascending, disjoint) and gets back, for each, the axis and the position of the cut, or "no cut"
+// when the centroids coincide along the widest axis.  Per level: range of every position (binary search), centroid
+// bounds and bins with atomics (whole-block ranges are reduced in LDS first), one thread per range walks the 3 x 31
+// candidate cuts in the host builder's order with its arithmetic (same cut, same ties), and one stable radix sort by
+// (range, side) moves every range's left side to its front - std::stable_partition for all ranges at once.
+namespace {
+
+constexpr int kSahBins = 32;
+constexpr int kBinWords = 7;  // count, min x y z, max x y z (ordered bits)
+
+__global__ void __launch_bounds__(kBlock) sahRangeOfKernel(int n, int ranges, const int32_t* __restrict__ rangeStart, const int32_t* __restrict__ rangeEnd,
+                                                           int32_t* __restrict__ rangeOf) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int lo = 0, hi = ranges;  // the last range that starts at or before i
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) / 2;
+        if (rangeStart[mid] <= i)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    rangeOf[i] = (ranges > 0 && rangeStart[lo] <= i && i < rangeEnd[lo]) ? lo : -1;
+}
+
+__global__ void __launch_bounds__(kBlock) sahInitKernel(int ranges, uint32_t* __restrict__ cb, uint32_t* __restrict__ bins) {
+    const size_t k = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t lo = orderedBits(FLT_MAX), hi = orderedBits(-FLT_MAX);
+    if (k < (size_t)ranges * 6) cb[k] = (k % 6) < 3 ? lo : hi;
+    if (k < (size_t)ranges * 3 * kSahBins * kBinWords) {
+        const int w = (int)(k % kBinWords);
+        bins[k] = w == 0 ? 0u : (w < 4 ? lo : hi);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) sahCentroidBoundsKernel(int n, const int32_t* __restrict__ rangeOf, const uint32_t* __restrict__ order,
+                                                                  const float4* __restrict__ bmin, const float4* __restrict__ bmax, uint32_t* cb) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int r = i < n ? rangeOf[i] : -1;
+    const bool active = r >= 0;
+    uint32_t lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+    if (active) {
+        const uint32_t prim = order[i];
+        float c[3];
+        centroidOf(bmin[prim], bmax[prim], c);
+        for (int a = 0; a < 3; ++a) lo[a] = hi[a] = orderedBits(c[a]);
+    }
+    const unsigned long long act = __ballot(active);
+    if (act == 0ull) return;
+    const int firstR = __shfl(r, __ffsll((long long)act) - 1, 64);
+    if (__ballot(active && r != firstR) == 0ull) {
+        // the wavefront's positions lie in one range: one lane touches memory
+        for (int off = 32; off > 0; off >>= 1)
+            for (int a = 0; a < 3; ++a) {
+                const uint32_t l = __shfl_xor(lo[a], off, 64), h = __shfl_xor(hi[a], off, 64);
+                lo[a] = l < lo[a] ? l : lo[a];
+                hi[a] = h > hi[a] ? h : hi[a];
+            }
+        if ((threadIdx.x & 63) == 0)
+            for (int a = 0; a < 3; ++a) {
+                atomicMin(cb + 6 * (size_t)firstR + a, lo[a]);
+                atomicMax(cb + 6 * (size_t)firstR + 3 + a, hi[a]);
+            }
+    } else if (active) {
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(cb + 6 * (size_t)r + a, lo[a]);
+            atomicMax(cb + 6 * (size_t)r + 3 + a, hi[a]);
+        }
+    }
+}
+
+// csrc/host/BVH.h binOf
+__device__ __forceinline__ int sahBinOf(float c, float lo, float extent) {
+    const int b = (int)((c - lo) / extent * (float)kSahBins);
+    return b < 0 ? 0 : (b >= kSahBins ? kSahBins - 1 : b);
+}
+
+__global__ void __launch_bounds__(kBlock) sahBinKernel(int n, const int32_t* __restrict__ rangeOf, const uint32_t* __restrict__ order,
+                                                       const float4* __restrict__ bmin, const float4* __restrict__ bmax, const uint32_t* __restrict__ cb,
+                                                       uint32_t* bins) {
+    __shared__ uint32_t sh[3 * kSahBins * kBinWords];
+    __shared__ int shRange, shMixed;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int r = i < n ? rangeOf[i] : -1;
+    if (threadIdx.x == 0) {
+        shRange = -2;
+        shMixed = 0;
+    }
+    __syncthreads();
+    if (r >= 0) {
+        const int seen = atomicCAS(&shRange, -2, r);
+        if (seen != -2 && seen != r) shMixed = 1;
+    }
+    __syncthreads();
+    if (shRange == -2) return;  // nothing to cut in this block
+    const bool local = shMixed == 0;  // every active position of the block lies in one range: bins in LDS first
+    if (local) {
+        const uint32_t lo = orderedBits(FLT_MAX), hi = orderedBits(-FLT_MAX);
+        for (int k = threadIdx.x; k < 3 * kSahBins * kBinWords; k += kBlock) {
+            const int w = k % kBinWords;
+            sh[k] = w == 0 ? 0u : (w < 4 ? lo : hi);
+        }
+        __syncthreads();
+    }
+    if (r >= 0) {
+        const uint32_t prim = order[i];
+        const float4 a = bmin[prim], b = bmax[prim];
+        float c[3];
+        centroidOf(a, b, c);
+        const uint32_t box[6] = {orderedBits(a.x), orderedBits(a.y), orderedBits(a.z), orderedBits(b.x), orderedBits(b.y), orderedBits(b.z)};
+        const uint32_t* bounds = cb + 6 * (size_t)r;
+        for (int dim = 0; dim < 3; ++dim) {
+            const float lo = fromOrderedBits(bounds[dim]), extent = fromOrderedBits(bounds[3 + dim]) - lo;
+            if (!(extent > 0.0f)) continue;
+            const int bin = sahBinOf(c[dim], lo, extent);
+            uint32_t* at = (local ? sh : bins + (size_t)r * 3 * kSahBins * kBinWords) + (dim * kSahBins + bin) * kBinWords;
+            atomicAdd(at, 1u);
+            for (int k = 0; k < 3; ++k) {
+                atomicMin(at + 1 + k, box[k]);
+                atomicMax(at + 4 + k, box[3 + k]);
+            }
+        }
+    }
+    if (local) {
+        __syncthreads();
+        uint32_t* out = bins + (size_t)shRange * 3 * kSahBins * kBinWords;
+        for (int k = threadIdx.x; k < 3 * kSahBins * kBinWords; k += kBlock) {
+            const int w = k % kBinWords;
+            const uint32_t v = sh[k];
+            if (sh[k - w] == 0u) continue;  // empty bin
+            if (w == 0)
+                atomicAdd(out + k, v);
+            else if (w < 4)
+                atomicMin(out + k, v);
+            else
+                atomicMax(out + k, v);
+        }
+    }
+}
+
+struct SahBox {
+    float lo[3], hi[3];
+};
+__device__ __forceinline__ SahBox sahEmpty() { return SahBox{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}}; }
+__device__ __forceinline__ void sahUnion(SahBox& acc, const uint32_t* bin) {
+    for (int k = 0; k < 3; ++k) {
+        const float l = fromOrderedBits(bin[1 + k]), h = fromOrderedBits(bin[4 + k]);
+        acc.lo[k] = l < acc.lo[k] ? l : acc.lo[k];
+        acc.hi[k] = h > acc.hi[k] ? h : acc.hi[k];
+    }
+}
+// csrc/host/BVH.h halfArea over BoundingBox::diagonal
+__device__ __forceinline__ float sahHalfArea(const SahBox& b) {
+    const float d0 = b.hi[0] - b.lo[0], d1 = b.hi[1] - b.lo[1], d2 = b.hi[2] - b.lo[2];
+    return d0 * d1 + d1 * d2 + d2 * d0;
+}
+
+// result[2 r] = axis | bin << 8, or -1: the centroids coincide along the widest axis (a leaf whatever its size);
+// result[2 r + 1] = position of the cut.  csrc/host/BVH.h recursive + sahPartition, candidate for candidate.
+__global__ void __launch_bounds__(kBlock) sahEvalKernel(int ranges, int threshold, const int32_t* __restrict__ rangeStart, const int32_t* __restrict__ rangeEnd,
+                                                        const uint32_t* __restrict__ cb, const uint32_t* __restrict__ bins, int32_t* __restrict__ result) {
+    const int r = blockIdx.x * kBlock + threadIdx.x;
+    if (r >= ranges) return;
+    const int start = rangeStart[r], cnt = rangeEnd[r] - start;
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = fromOrderedBits(cb[6 * (size_t)r + a]);
+        hi[a] = fromOrderedBits(cb[6 * (size_t)r + 3 + a]);
+    }
+    const float d0 = hi[0] - lo[0], d1 = hi[1] - lo[1], d2 = hi[2] - lo[2];
+    const int widest = (d0 > d1 && d0 > d2) ? 0 : (d1 > d2 ? 1 : 2);  // BoundingBox::maxExtent
+    if (hi[widest] == lo[widest]) {
+        result[2 * r] = -1;
+        result[2 * r + 1] = start;
+        return;
+    }
+    float bestCost = FLT_MAX;
+    int bestDim = -1, bestBin = -1, bestLeft = 0;
+    const bool wantTwoLeaves = cnt <= 2 * threshold;
+    bool haveTwoLeaves = false;
+    for (int dim = 0; dim < 3; ++dim) {
+        if (!(hi[dim] - lo[dim] > 0.0f)) continue;
+        const uint32_t* row = bins + ((size_t)r * 3 + dim) * kSahBins * kBinWords;
+        float rightArea[kSahBins];
+        int rightCount[kSahBins];
+        SahBox acc = sahEmpty();
+        int k = 0;
+        for (int b = kSahBins - 1; b > 0; --b) {
+            const uint32_t* bin = row + b * kBinWords;
+            if (bin[0]) sahUnion(acc, bin);
+            k += (int)bin[0];
+            rightArea[b] = k ? sahHalfArea(acc) : 0.0f;
+            rightCount[b] = k;
+        }
+        acc = sahEmpty();
+        k = 0;
+        for (int b = 1; b < kSahBins; ++b) {
+            const uint32_t* bin = row + (b - 1) * kBinWords;
+            if (bin[0]) sahUnion(acc, bin);
+            k += (int)bin[0];
+            if (k == 0 || rightCount[b] == 0) continue;
+            const bool twoLeaves = k <= threshold && rightCount[b] <= threshold;
+            if (wantTwoLeaves && !twoLeaves && haveTwoLeaves) continue;
+            const float cost = wantTwoLeaves && twoLeaves ? sahHalfArea(acc) + rightArea[b] : sahHalfArea(acc) * (float)k + rightArea[b] * (float)rightCount[b];
+            if (cost < bestCost || (wantTwoLeaves && twoLeaves && !haveTwoLeaves)) {
+                bestCost = cost;
+                bestDim = dim;
+                bestBin = b;
+                bestLeft = k;
+                haveTwoLeaves = wantTwoLeaves && twoLeaves;
+            }
+        }
+    }
+    // (bestDim >= 0: along the widest axis bins 0 and 31 are both occupied)
+    result[2 * r] = bestDim < 0 ? -1 : (bestDim | (bestBin << 8));
+    result[2 * r + 1] = start + bestLeft;
+}
+
+// Sort keys: 2 * (start of the range) + side for positions of ranges that are cut, 2 * position for all others - ranges
+// stay where they are, and inside a range the left side moves to the front in its old order.
+__global__ void __launch_bounds__(kBlock) sahKeyKernel(int n, const int32_t* __restrict__ rangeOf, const int32_t* __restrict__ rangeStart,
+                                                       const uint32_t* __restrict__ order, const float4* __restrict__ bmin, const float4* __restrict__ bmax,
+                                                       const uint32_t* __restrict__ cb, const int32_t* __restrict__ result, uint64_t* __restrict__ keys) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int r = rangeOf[i];
+    const int code = r >= 0 ? result[2 * r] : -1;
+    if (code < 0) {
+        keys[i] = 2ull * (uint64_t)i;
+        return;
+    }
+    const int dim = code & 3, bin = code >> 8;
+    const uint32_t prim = order[i];
+    float c[3];
+    centroidOf(bmin[prim], bmax[prim], c);
+    const float lo = fromOrderedBits(cb[6 * (size_t)r + dim]), extent = fromOrderedBits(cb[6 * (size_t)r + 3 + dim]) - lo;
+    keys[i] = 2ull * (uint64_t)rangeStart[r] + (sahBinOf(c[dim], lo, extent) < bin ? 0ull : 1ull);
+}
+
+}  // namespace
+
+struct RtSahBuild {
+    int n = 0, maxRanges = 0;
+    float4 *bmin = nullptr, *bmax = nullptr;
+    uint32_t *orderA = nullptr, *orderB = nullptr, *cb = nullptr, *bins = nullptr;
+    uint64_t *keysA = nullptr, *keysB = nullptr;
+    int32_t *rangeOf = nullptr, *rangeStart = nullptr, *rangeEnd = nullptr, *result = nullptr;
+    void* temp = nullptr;
+};
+
+void rtk_sah_end(RtSahBuild* b) {
+    if (!b) return;
+    void* all[] = {b->bmin, b->bmax, b->orderA, b->orderB, b->cb, b->bins, b->keysA, b->keysB, b->rangeOf, b->rangeStart, b->rangeEnd, b->result, b->temp};
+    for (void* p : all)
+        if (p) (void)hipFree(p);
+    delete b;
+}
+
+int rtk_sah_begin(int n, int threshold, const float* hostBmin, const float* hostBmax, RtSahBuild** out, void* streamPtr) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(streamPtr);
+    RtSahBuild* b = new RtSahBuild();
+    b->n = n;
+    b->maxRanges = n / (threshold + 1) + 1;  // a range that is cut holds more than `threshold` primitives
+    auto cleanup = [&]() { rtk_sah_end(b); };
+    RTB_HIP(hipMalloc(&b->bmin, (size_t)n * sizeof(float4)));
+    RTB_HIP(hipMalloc(&b->bmax, (size_t)n * sizeof(float4)));
+    RTB_HIP(hipMalloc(&b->orderA, (size_t)n * 4));
+    RTB_HIP(hipMalloc(&b->orderB, (size_t)n * 4));
+    RTB_HIP(hipMalloc(&b->keysA, (size_t)n * 8));
+    RTB_HIP(hipMalloc(&b->keysB, (size_t)n * 8));
+    RTB_HIP(hipMalloc(&b->rangeOf, (size_t)n * 4));
+    RTB_HIP(hipMalloc(&b->rangeStart, (size_t)b->maxRanges * 4));
+    RTB_HIP(hipMalloc(&b->rangeEnd, (size_t)b->maxRanges * 4));
+    RTB_HIP(hipMalloc(&b->result, (size_t)b->maxRanges * 8));
+    RTB_HIP(hipMalloc(&b->cb, (size_t)b->maxRanges * 6 * 4));
+    RTB_HIP(hipMalloc(&b->bins, (size_t)b->maxRanges * 3 * kSahBins * kBinWords * 4));
+    RTB_HIP(hipMalloc(&b->temp, radixSortTempBytes(n)));
+    RTB_HIP(hipMemcpyAsync(b->bmin, hostBmin, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, stream));
+    RTB_HIP(hipMemcpyAsync(b->bmax, hostBmax, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(iotaKernel, dim3(blocksFor(n)), dim3(kBlock), 0, stream, n, b->orderA);
+    RTB_HIP(hipStreamSynchronize(stream));
+    *out = b;
+    return 0;
+}
+
+// One level: `ranges` ranges [hostStart[r], hostEnd[r]) in ascending order, each with more than `threshold` primitives.
+// hostResult[2 r] = axis | bin << 8 or -1 (no cut: all centroids coincide along the widest axis), hostResult[2 r + 1] =
+// position of the cut; the primitives of every range that is cut are in their new order when the call returns.
+int rtk_sah_level(RtSahBuild* b, int ranges, int threshold, const int32_t* hostStart, const int32_t* hostEnd, int32_t* hostResult, void* streamPtr) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(streamPtr);
+    if (ranges < 1) return 0;
+    if (ranges > b->maxRanges) return (int)hipErrorInvalidValue;
+    auto cleanup = [] {};
+    const int n = b->n, grid = blocksFor(n);
+    RTB_HIP(hipMemcpyAsync(b->rangeStart, hostStart, (size_t)ranges * 4, hipMemcpyHostToDevice, stream));
+    RTB_HIP(hipMemcpyAsync(b->rangeEnd, hostEnd, (size_t)ranges * 4, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(sahRangeOfKernel, dim3(grid), dim3(kBlock), 0, stream, n, ranges, b->rangeStart, b->rangeEnd, b->rangeOf);
+    hipLaunchKernelGGL(sahInitKernel, dim3(blocksFor((long long)ranges * 3 * kSahBins * kBinWords)), dim3(kBlock), 0, stream, ranges, b->cb, b->bins);
+    hipLaunchKernelGGL(sahCentroidBoundsKernel, dim3(grid), dim3(kBlock), 0, stream, n, b->rangeOf, b->orderA, b->bmin, b->bmax, b->cb);
+    hipLaunchKernelGGL(sahBinKernel, dim3(grid), dim3(kBlock), 0, stream, n, b->rangeOf, b->orderA, b->bmin, b->bmax, b->cb, b->bins);
+    hipLaunchKernelGGL(sahEvalKernel, dim3(blocksFor(ranges)), dim3(kBlock), 0, stream, ranges, threshold, b->rangeStart, b->rangeEnd, b->cb, b->bins, b->result);
+    hipLaunchKernelGGL(sahKeyKernel, dim3(grid), dim3(kBlock), 0, stream, n, b->rangeOf, b->rangeStart, b->orderA, b->bmin, b->bmax, b->cb, b->result, b->keysA);
+    int bits = 1;
+    while ((2ull * (uint64_t)n) >> bits) ++bits;
+    if (radixSortPairs(b->temp, b->keysA, b->keysB, b->orderA, b->orderB, n, bits, stream)) {
+        std::swap(b->orderA, b->orderB);
+        std::swap(b->keysA, b->keysB);
+    }
+    RTB_HIP(hipMemcpyAsync(hostResult, b->result, (size_t)ranges * 8, hipMemcpyDeviceToHost, stream));
+    RTB_HIP(hipStreamSynchronize(stream));
+    RTB_HIP(hipGetLastError());
+    return 0;
+}
+
+// The primitive at every position, after the last level.
+int rtk_sah_order(RtSahBuild* b, uint32_t* hostOrder, void* streamPtr) {
+    hipStream_t stream = reinterpret_cast<hipStream_t>(streamPtr);
+    auto cleanup = [] {};
+    RTB_HIP(hipMemcpyAsync(hostOrder, b->orderA, (size_t)b->n * 4, hipMemcpyDeviceToHost, stream));
+    RTB_HIP(hipStreamSynchronize(stream));
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 // Bounds refit of a tree that is already in the blob (rt_set_upload_refit).  The reference's builder starts every box
 // union from an "empty" box whose max is FLT_MIN (cudaTracer/BoundingBox.cuh:25-27, cudaTracer/BVH.h:90-96), so every
 // box over negative coordinates reaches up to 0.  Topology, split axes and leaf contents stay as the caller built them;

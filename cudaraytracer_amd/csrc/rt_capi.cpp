@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -62,6 +63,7 @@ struct BuildParams {
     int threshold = 10;
     int tightBounds = 1;
     bool rebuildAll = false;  // rt_set_upload_rebuild: also meshes that arrive WITH nodes get their BVH on the device
+    int splitRule = RT_BVH_MEDIAN_CUT;  // rt_set_device_bvh_rule
 };
 // true if this mesh's BVH is built on the device at upload (its node array, if it has one, is not looked at)
 inline bool builtOnDevice(const RtMesh& m, const BuildParams* build) { return (m.nodeCnt == 0 && !m.nodes) || (build && build->rebuildAll); }
@@ -998,6 +1000,196 @@ int refitOnDevice(rt_ctx* ctx, rt_scene* sc, const unsigned char* hostBlob, cons
 }
 }  // namespace
 
+namespace {
+// The mesh BVH of rt_mesh_bvh_build(RT_BVH_BINNED_SAH, tight bounds) with the cuts decided on the device
+// (rt_set_device_bvh_rule): same node array, same leaf order.  The host keeps the tree - its shape depends on the data -
+// and drives the device level by level (kernels/rt_bvh_build.hip, "Surface-area cuts"); boxes are formed here, by the
+// host builder's own functions, from the order the device returns.
+int deviceSahBuild(rt_ctx* ctx, const RtMesh& m, int threshold, std::vector<RtLinearNode>& nodes, std::vector<RtTriangle>& ordered, std::string* err) {
+    using rt::BoundingBox;
+    const int n = m.triangleCnt;
+    const bool verbose = std::getenv("RT_TRACE_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    double tBoxes = 0, tLevels = 0;
+    int levels = 0;
+    if (n < 1 || !m.triangles || m.vertexCnt < 1 || !m.vertices) {
+        *err = "mesh with missing triangles or vertices";
+        return RT_ERR_INVALID;
+    }
+    for (int t = 0; t < n; ++t)
+        for (int k = 0; k < 3; ++k)
+            if (m.triangles[t].i[k] < 0 || m.triangles[t].i[k] >= m.vertexCnt) {
+                *err = "triangle vertex index out of range";
+                return RT_ERR_INVALID;
+            }
+    // primitive boxes as csrc/host/BVH.h triangleBox(TIGHT_BOUNDS) forms them, on as many threads as the host builder takes
+    std::vector<BoundingBox> boxes((size_t)n);
+    {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int threads = n < (1 << 16) ? 1 : (int)std::min(hw ? hw : 1u, 16u);
+        auto part = [&](int k) {
+            const size_t from = (size_t)n * k / threads, to = (size_t)n * (k + 1) / threads;
+            for (size_t t = from; t < to; ++t) {
+                BoundingBox b = rt::BVH::emptyBox(rt::BVH::TIGHT_BOUNDS);
+                for (int c = 0; c < 3; ++c) {
+                    const float* p = m.vertices[m.triangles[t].i[c]].position;
+                    b = BoundingBox::unionn(b, rt::Vec3f(p[0], p[1], p[2]));
+                }
+                boxes[t] = b;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int k = 1; k < threads; ++k) pool.emplace_back(part, k);
+        part(0);
+        for (std::thread& t : pool) t.join();
+    }
+    tBoxes = now() - t0;
+    struct Node {
+        int start, end, orderedBase, axis, first, second;  // children: indices into `tree`, -1 for a leaf
+    };
+    std::vector<Node> tree;
+    tree.push_back(Node{0, n, 0, 0, -1, -1});
+    std::vector<uint32_t> order((size_t)n);
+    if (n > threshold) {
+        std::vector<float> lo((size_t)n * 4), hi((size_t)n * 4);
+        for (int t = 0; t < n; ++t)
+            for (int k = 0; k < 3; ++k) {
+                lo[(size_t)t * 4 + k] = boxes[t].bbmin[k];
+                hi[(size_t)t * 4 + k] = boxes[t].bbmax[k];
+            }
+        RtSahBuild* build = nullptr;
+        hipError_t e = (hipError_t)rtk_sah_begin(n, threshold, lo.data(), hi.data(), &build, ctx->stream);
+        std::vector<int> active{0};  // nodes of `tree` still to be cut, in ascending order of their ranges
+        std::vector<int32_t> starts, ends, result;
+        while (e == hipSuccess && !active.empty()) {
+            starts.clear();
+            ends.clear();
+            for (int k : active) {
+                starts.push_back(tree[k].start);
+                ends.push_back(tree[k].end);
+            }
+            result.assign(active.size() * 2, 0);
+            e = (hipError_t)rtk_sah_level(build, (int)active.size(), threshold, starts.data(), ends.data(), result.data(), ctx->stream);
+            if (e != hipSuccess) break;
+            std::vector<int> next;
+            for (size_t a = 0; a < active.size(); ++a) {
+                const int k = active[a], code = result[2 * a], mid = result[2 * a + 1];
+                if (code < 0) continue;  // the centroids coincide: a leaf, whatever it holds
+                const Node nd = tree[k];
+                if (mid <= nd.start || mid >= nd.end) {
+                    *err = "BVH build on the device: a cut outside its range";
+                    rtk_sah_end(build);
+                    return RT_ERR_DEVICE;
+                }
+                // csrc/host/BVH.h halves: the second half's leaves take the front of the range's ordered slots
+                const int first = (int)tree.size();
+                tree.push_back(Node{nd.start, mid, nd.orderedBase + (nd.end - mid), 0, -1, -1});
+                tree.push_back(Node{mid, nd.end, nd.orderedBase, 0, -1, -1});
+                tree[k].axis = code & 3;
+                tree[k].first = first;
+                tree[k].second = first + 1;
+                if (mid - nd.start > threshold) next.push_back(first);
+                if (nd.end - mid > threshold) next.push_back(first + 1);
+            }
+            active.swap(next);
+            ++levels;
+        }
+        tLevels = now() - t0 - tBoxes;
+        if (e == hipSuccess) e = (hipError_t)rtk_sah_order(build, order.data(), ctx->stream);
+        rtk_sah_end(build);
+        if (e != hipSuccess) {
+            *err = std::string("BVH build on the device: ") + hipGetErrorString(e);
+            return RT_ERR_DEVICE;
+        }
+    } else {
+        for (int t = 0; t < n; ++t) order[t] = (uint32_t)t;
+    }
+    // depth-first node array (csrc/host/BVH.h flattenBvhTree): node, first subtree, second subtree; an interior node names
+    // its second child.  Children are laid out before their parent's box is formed, so one sweep from the back is bottom-up.
+    nodes.assign(tree.size(), RtLinearNode{});
+    ordered.assign((size_t)n, RtTriangle{});
+    std::vector<int> slotOf(tree.size(), -1);
+    {
+        std::vector<int> stack{0};
+        int at = 0;
+        while (!stack.empty()) {
+            const int k = stack.back();
+            stack.pop_back();
+            slotOf[k] = at++;
+            if (tree[k].first >= 0) {
+                stack.push_back(tree[k].second);
+                stack.push_back(tree[k].first);
+            }
+        }
+    }
+    std::vector<int> bySlot(tree.size());
+    for (size_t k = 0; k < tree.size(); ++k) bySlot[slotOf[k]] = (int)k;
+    for (const Node& nd : tree)
+        if (nd.first < 0 && nd.end - nd.start > 65535) {
+            *err = "BvhFactory: leaf exceeds the 16-bit primitive count of LinearNode";
+            return RT_ERR_LIMIT;
+        }
+    {
+        // the leaves: boxes and ordered triangles, each leaf on its own - on several threads for a large mesh
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int threads = n < (1 << 16) ? 1 : (int)std::min(hw ? hw : 1u, 16u);
+        auto part = [&](int k) {
+            const size_t from = tree.size() * k / threads, to = tree.size() * (k + 1) / threads;
+            for (size_t t = from; t < to; ++t) {
+                const Node& nd = tree[t];
+                if (nd.first >= 0) continue;
+                BoundingBox bb = rt::BVH::emptyBox(rt::BVH::TIGHT_BOUNDS);
+                for (int i = nd.start; i < nd.end; ++i) {
+                    bb = BoundingBox::unionn(bb, boxes[order[i]]);
+                    ordered[(size_t)nd.orderedBase + (i - nd.start)] = m.triangles[order[i]];
+                }
+                RtLinearNode& out = nodes[slotOf[t]];
+                out.offset = nd.orderedBase;
+                out.primCnt = (uint16_t)(nd.end - nd.start);
+                for (int c = 0; c < 3; ++c) {
+                    out.bbmin[c] = bb.bbmin[c];
+                    out.bbmax[c] = bb.bbmax[c];
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int k = 1; k < threads; ++k) pool.emplace_back(part, k);
+        part(0);
+        for (std::thread& t : pool) t.join();
+    }
+    for (int slot = (int)tree.size() - 1; slot >= 0; --slot) {
+        const Node& nd = tree[bySlot[slot]];
+        RtLinearNode& out = nodes[slot];
+        BoundingBox bb = rt::BVH::emptyBox(rt::BVH::TIGHT_BOUNDS);
+        if (nd.first < 0) {
+            continue;
+        } else {
+            const RtLinearNode &a = nodes[slotOf[nd.first]], &b = nodes[slotOf[nd.second]];
+            BoundingBox ba, bc;
+            for (int c = 0; c < 3; ++c) {
+                ba.bbmin[c] = a.bbmin[c];
+                ba.bbmax[c] = a.bbmax[c];
+                bc.bbmin[c] = b.bbmin[c];
+                bc.bbmax[c] = b.bbmax[c];
+            }
+            bb = BoundingBox::unionn(ba, bc);
+            out.offset = slotOf[nd.second];
+            out.primCnt = 0;
+            out.axis = (uint8_t)nd.axis;
+        }
+        for (int c = 0; c < 3; ++c) {
+            out.bbmin[c] = bb.bbmin[c];
+            out.bbmax[c] = bb.bbmax[c];
+        }
+    }
+    if (verbose)
+        std::fprintf(stderr, "  surface-area build: boxes %.3f s, %d levels on the device %.3f s, nodes and leaf order %.3f s\n", tBoxes, levels, tLevels,
+                     now() - t0 - tBoxes - tLevels);
+    return RT_OK;
+}
+}  // namespace
+
 rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
     if (!ctx) return nullptr;
     std::vector<unsigned char> host;
@@ -1008,7 +1200,43 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
     double t0 = now();
     // with rt_set_upload_refit the blob is packed as it came and its boxes are recomputed on the device, below
     const bool refitHere = ctx->uploadRefit || ctx->bvhBuild.rebuildAll;  // (a rebuild gives the scene BVH true boxes too)
-    int r = packScene(desc, host, &err, &ctx->bvhBuild, &builds, false, /*boxesWillBeRefit=*/refitHere);
+    // Surface-area cuts: the meshes that get their BVH on the device get it BEFORE the blob is laid out (the size of
+    // such a tree is not known beforehand) and go into the blob like meshes that came with nodes.
+    RtSceneDesc local;
+    std::vector<RtMesh> localMeshes;
+    std::vector<std::vector<RtLinearNode>> builtNodes;
+    std::vector<std::vector<RtTriangle>> builtTriangles;
+    BuildParams packBuild = ctx->bvhBuild;
+    if (desc && ctx->bvhBuild.splitRule == RT_BVH_BINNED_SAH && desc->meshCnt > 0 && desc->meshes) {
+        if (!ctx->bvhBuild.tightBounds) {
+            fail(ctx, RT_ERR_INVALID, "surface-area cuts on the device are made on true bounds: rt_set_device_bvh(ctx, threshold, 1)");
+            return nullptr;
+        }
+        if (bind(ctx)) return nullptr;
+        localMeshes.assign(desc->meshes, desc->meshes + desc->meshCnt);
+        builtNodes.resize(desc->meshCnt);
+        builtTriangles.resize(desc->meshCnt);
+        for (int mi = 0; mi < desc->meshCnt; ++mi) {
+            if (!builtOnDevice(desc->meshes[mi], &ctx->bvhBuild)) continue;
+            const double t1 = now();
+            const int rr = deviceSahBuild(ctx, desc->meshes[mi], ctx->bvhBuild.threshold, builtNodes[mi], builtTriangles[mi], &err);
+            if (rr != RT_OK) {
+                fail(ctx, rr, "mesh %d: %s", mi, err.c_str());
+                return nullptr;
+            }
+            if (verbose)
+                std::fprintf(stderr, "rt_scene_upload: BVH of mesh %d (%d triangles, %zu nodes) cut by surface area on the device in %.3f s\n", mi,
+                             desc->meshes[mi].triangleCnt, builtNodes[mi].size(), now() - t1);
+            localMeshes[mi].nodes = builtNodes[mi].data();
+            localMeshes[mi].nodeCnt = (int)builtNodes[mi].size();
+            localMeshes[mi].triangles = builtTriangles[mi].data();
+        }
+        local = *desc;
+        local.meshes = localMeshes.data();
+        desc = &local;
+        packBuild.rebuildAll = false;  // every mesh carries its nodes now
+    }
+    int r = packScene(desc, host, &err, &packBuild, &builds, false, /*boxesWillBeRefit=*/refitHere);
     if (verbose) std::fprintf(stderr, "rt_scene_upload: packed %zu bytes in %.3f s\n", host.size(), now() - t0);
     if (r != RT_OK) {
         fail(ctx, r, "%s", err.c_str());
@@ -1105,6 +1333,13 @@ int rt_set_device_bvh(rt_ctx* ctx, int threshold, int tightBounds) {
     if (threshold < 1 || threshold > RT_REF_MAX_LEAF_PRIMS) return fail(ctx, RT_ERR_INVALID, "leaf threshold must be in 1..%d", RT_REF_MAX_LEAF_PRIMS);
     ctx->bvhBuild.threshold = threshold;
     ctx->bvhBuild.tightBounds = tightBounds ? 1 : 0;
+    return RT_OK;
+}
+
+int rt_set_device_bvh_rule(rt_ctx* ctx, int splitRule) {
+    if (!ctx) return RT_ERR_INVALID;
+    if (splitRule != RT_BVH_MEDIAN_CUT && splitRule != RT_BVH_BINNED_SAH) return fail(ctx, RT_ERR_INVALID, "unknown split rule");
+    ctx->bvhBuild.splitRule = splitRule;
     return RT_OK;
 }
 

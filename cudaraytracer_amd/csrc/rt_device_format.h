@@ -265,6 +265,14 @@ struct RtBvhBuildJob {
 // Runs the build on `stream` and waits for it.  Returns a hipError_t value.
 int rtk_build_mesh_bvh(const RtBvhBuildJob* job, void* stream);
 
+// Surface-area cuts on the device, driven level by level from the host (kernels/rt_bvh_build.hip, "Surface-area cuts"):
+// `hostBmin` / `hostBmax` are the primitives' boxes as float4 arrays.  All return a hipError_t value and wait for `stream`.
+struct RtSahBuild;
+int rtk_sah_begin(int n, int threshold, const float* hostBmin, const float* hostBmax, RtSahBuild** out, void* stream);
+int rtk_sah_level(RtSahBuild* b, int ranges, int threshold, const int32_t* hostStart, const int32_t* hostEnd, int32_t* hostResult, void* stream);
+int rtk_sah_order(RtSahBuild* b, uint32_t* hostOrder, void* stream);
+void rtk_sah_end(RtSahBuild* b);
+
 // Bounds refit of one BVH inside the blob (rt_set_upload_refit): `pairs` = device address of the tree's pair records,
 // `pairBase` = their blob offset / 64, `depth` = levels below the root.  A mesh BVH passes `records` (the blob's
 // triangle-record array) and `vertices` (the mesh's vertex array): its leaves get the exact bounds of their triangles.

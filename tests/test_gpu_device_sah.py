@@ -1,0 +1,80 @@
+"""Mesh BVHs cut by the binned surface-area heuristic ON THE DEVICE (rt_set_device_bvh_rule) against the host builder with
+the same rule (csrc/host/BVH.h sahPartition through rt_mesh_bvh_build): the blobs must be identical byte for byte -
+same nodes, same boxes, same leaf order - and frames must match the oracle."""
+import numpy as np
+import pytest
+
+import cudaraytracer_amd as rt
+from parity import assert_parity
+from test_gpu_device_bvh import mesh_sections
+
+pytestmark = pytest.mark.gpu
+
+
+def blob_of(ctx, dscene):
+    ptr, n = ctx.scene_blob(dscene)
+    return ctx.download(ptr, (n,), np.uint8)
+
+
+@pytest.mark.parametrize("name,size,threshold", [("soup", 50000, 8), ("soup", 20011, 4), ("soup", 7, 8), ("soup", 11, 8), ("soup", 300, 1),
+                                                 ("heightfield", 30000, 8), ("heightfield", 200000, 10), ("cubes", 6, 8), ("soup", 1000000, 8)])
+def test_device_cut_tree_is_the_host_builders_tree(gpu_ctx, name, size, threshold):
+    w, h = 64, 48
+    host = rt.HostScene(name, w, h, size, 1, 0, tight_bvh=True, sah_bvh=True, leaf_threshold=threshold)
+    dev = rt.HostScene(name, w, h, size, 1, 0, tight_bvh=True, device_bvh=True)
+    gpu_ctx.set_device_bvh(threshold, True)
+    gpu_ctx.set_device_bvh_rule(sah=True)
+    a = b = None
+    try:
+        a = gpu_ctx.upload(host)
+        b = gpu_ctx.upload(dev)
+        blob_a, blob_b = blob_of(gpu_ctx, a), blob_of(gpu_ctx, b)
+        assert len(blob_a) == len(blob_b)
+        if name == "cubes":
+            # indexed meshes: the generator forms per-face tangents in triangle order (cudaTracer/CudaMesh.h:106-130), which the
+            # host-built scene has reordered by then - the vertex arrays differ in the sign of zeros; trees and records must not
+            assert np.array_equal(blob_a[:256], blob_b[:256])
+            for mesh in range(size * size):
+                nodes_a, tris_a, _ = mesh_sections(blob_a, mesh)
+                nodes_b, tris_b, _ = mesh_sections(blob_b, mesh)
+                assert np.array_equal(nodes_a, nodes_b) and np.array_equal(tris_a, tris_b), mesh
+        else:
+            assert np.array_equal(blob_a, blob_b)
+    finally:
+        gpu_ctx.set_device_bvh_rule(sah=False)
+        gpu_ctx.set_device_bvh(10, True)
+        for s in (a, b):
+            if s is not None:
+                gpu_ctx.free_scene(s)
+
+
+@pytest.mark.parametrize("name,size,depth", [("soup", 100000, 0), ("mixed", 0, 3), ("cubes", 8, 2)])
+def test_frames_match_the_oracle(gpu_ctx, oracle, synthetic_assets, name, size, depth):
+    """The handed-over trees (median cut, reference bounds) are thrown away at upload and cut again by surface area on
+    the device (rt_set_upload_rebuild + rt_set_device_bvh_rule): every hit key as the oracle has it on the caller's trees."""
+    w, h = 160, 96
+    scene = rt.HostScene(name, w, h, size, 2, depth, asset_dir=synthetic_assets if name == "mixed" else None, tight_bvh=True)
+    ref_rgba, ref_keys, ref_cnt = oracle.render(scene.desc, scene.opts, scene.camera, w, h, threads=8, shadow_any_hit=True)
+    gpu_ctx.set_device_bvh(8, True)
+    gpu_ctx.set_device_bvh_rule(sah=True)
+    gpu_ctx.set_upload_rebuild(True)
+    try:
+        rgba, keys, cnt = gpu_ctx.render_frame(scene, want_keys=True, want_counters=True)
+    finally:
+        gpu_ctx.set_upload_rebuild(False)
+        gpu_ctx.set_device_bvh_rule(sah=False)
+        gpu_ctx.set_device_bvh(10, True)
+    assert_parity(rgba, keys, ref_rgba, ref_keys, radiance_fraction=1.0 if name == "soup" else 0.9998)
+    assert (cnt["primary"], cnt["shadow"], cnt["secondary"]) == (ref_cnt["primary"], ref_cnt["shadow"], ref_cnt["secondary"])
+
+
+def test_reference_bounds_are_refused(gpu_ctx):
+    dev = rt.HostScene("soup", 32, 32, 1000, 1, 0, tight_bvh=True, device_bvh=True)
+    gpu_ctx.set_device_bvh(8, False)
+    gpu_ctx.set_device_bvh_rule(sah=True)
+    try:
+        with pytest.raises(rt.RtError):
+            gpu_ctx.upload(dev)
+    finally:
+        gpu_ctx.set_device_bvh_rule(sah=False)
+        gpu_ctx.set_device_bvh(10, True)

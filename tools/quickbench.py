@@ -32,6 +32,7 @@ ap.add_argument("--tile-order", type=int, default=-1)
 ap.add_argument("--cost-first", type=float, default=0.0,
                 help="with --cost-order: only this fraction of the tiles (the most expensive) goes first, in order of falling cost; the rest keeps the centre-out order")
 ap.add_argument("--device-bvh", action="store_true")
+ap.add_argument("--device-sah", action="store_true", help="with --device-bvh: the device cuts by the binned surface-area heuristic (rt_set_device_bvh_rule), leaves of 8")
 ap.add_argument("--sah", action="store_true", help="mesh BVHs cut by the binned surface-area heuristic (host build)")
 ap.add_argument("--leaf", type=int, default=0, help="most triangles in a leaf (0: builder default)")
 ap.add_argument("--assets", default=None, help="asset directory for the mixed / barrel scenes; 'synthetic' writes stand-ins to a temp dir")
@@ -63,7 +64,8 @@ with rt.Context(0) as ctx:
         ctx.set_frames_in_flight(a.frames_in_flight)
     if a.lds_stack:
         ctx.set_lds_stack(a.lds_stack)
-    ctx.set_device_bvh(a.leaf or 10, not a.reference_bvh)
+    ctx.set_device_bvh(a.leaf or (8 if a.device_sah else 10), not a.reference_bvh)
+    ctx.set_device_bvh_rule(a.device_sah)
     ctx.sync()
     t = time.time()
     ds = ctx.upload(scene)
