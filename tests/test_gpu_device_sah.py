@@ -78,3 +78,49 @@ def test_reference_bounds_are_refused(gpu_ctx):
     finally:
         gpu_ctx.set_device_bvh_rule(sah=False)
         gpu_ctx.set_device_bvh(10, True)
+
+
+def test_clumps_of_coinciding_centroids(gpu_ctx, rtlib):
+    """Triangles whose boxes - hence centroids - coincide: the host builder with the surface-area rule stops at a range
+    whose centroids all coincide along the widest axis and makes it one leaf, whatever its size (csrc/host/BVH.h, after
+    cudaTracer/BVH.h:126-128).  The device makes the same tree: the two scenes' blobs are identical."""
+    import hand_scenes as hs
+    from test_gpu_fuzz import bvh_of
+
+    rng = np.random.default_rng(5)
+    tris = []
+    for c in ((-1.5, 0.0, 6.0), (1.5, 0.5, 7.0), (0.0, -1.0, 9.0)):
+        c = np.float32(c)
+        for k in range(25):  # 25 triangles per clump, all with the box [c - 1, c + 1]
+            a, b = rng.uniform(-1, 1, 2)
+            p = np.float32([[-1, a, -1], [1, -1, b], [b, 1, 1]]) + c
+            tris.append(hs.tri(*[tuple(float(x) for x in v) for v in p]))
+    for k in range(40):
+        c = rng.uniform(-3, 3, 3) + np.float32([0, 0, 8])
+        p = np.float32(c + rng.uniform(-0.7, 0.7, (3, 3)))
+        tris.append(hs.tri(*[tuple(float(x) for x in v) for v in p]))
+    ordered, spec = bvh_of(rtlib, tris, 1, 8, 1)  # RT_BVH_BINNED_SAH, leaves of 8, tight bounds
+    assert max(n[3] for n in spec) > 8  # a clump stayed one leaf
+    lights = [((0, 4, 0), (1, 1, 1), 8.0)]
+    host_scene = hs.Scene(32, 32, [hs.Mesh(ordered, nodes=spec)], lights=lights)
+    # the caller's order must not matter to the tree's shape; leaf slots follow the stable partition of THIS order
+    dev_scene = hs.Scene(32, 32, [hs.Mesh(tris, device_bvh=True)], lights=lights)
+    gpu_ctx.set_device_bvh(8, True)
+    gpu_ctx.set_device_bvh_rule(sah=True)
+    a = b = None
+    try:
+        import ctypes as C
+        a = gpu_ctx.upload(C.pointer(host_scene.desc))
+        b = gpu_ctx.upload(C.pointer(dev_scene.desc))
+        blob_a, blob_b = blob_of(gpu_ctx, a), blob_of(gpu_ctx, b)
+        nodes_a, tris_a, _ = mesh_sections(blob_a)
+        nodes_b, tris_b, _ = mesh_sections(blob_b)
+        assert np.array_equal(nodes_a, nodes_b)
+        # triangle records: position and edges (the vertex numbers differ: hand_scenes numbers vertices by list position)
+        assert np.array_equal(tris_a[:, :9], tris_b[:, :9])
+    finally:
+        gpu_ctx.set_device_bvh_rule(sah=False)
+        gpu_ctx.set_device_bvh(10, True)
+        for s in (a, b):
+            if s is not None:
+                gpu_ctx.free_scene(s)
