@@ -542,28 +542,28 @@ __global__ void __launch_bounds__(kBlock) sahCentroidBoundsKernel(int n, const i
         centroidOf(bmin[prim], bmax[prim], c);
         for (int a = 0; a < 3; ++a) lo[a] = hi[a] = orderedBits(c[a]);
     }
-    const unsigned long long act = __ballot(active);
-    if (act == 0ull) return;
-    const int firstR = __shfl(r, __ffsll((long long)act) - 1, 64);
-    if (__ballot(active && r != firstR) == 0ull) {
-        // the wavefront's positions lie in one range: one lane touches memory
-        for (int off = 32; off > 0; off >>= 1)
-            for (int a = 0; a < 3; ++a) {
-                const uint32_t l = __shfl_xor(lo[a], off, 64), h = __shfl_xor(hi[a], off, 64);
+    if (__ballot(active) == 0ull) return;
+    // Positions of one range are consecutive, so inside a wavefront they form a run of lanes: a segmented scan leaves the
+    // run's bounds in its last lane, and only that lane touches memory (one lane per wavefront near the root, one per
+    // ten or twenty positions at the bottom of the tree, instead of every lane).
+    const int lane = threadIdx.x & 63;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int rr = __shfl_up(r, off, 64);
+        const bool same = lane >= off && rr == r;
+        for (int a = 0; a < 3; ++a) {
+            const uint32_t l = __shfl_up(lo[a], off, 64), h = __shfl_up(hi[a], off, 64);
+            if (same) {
                 lo[a] = l < lo[a] ? l : lo[a];
                 hi[a] = h > hi[a] ? h : hi[a];
             }
-        if ((threadIdx.x & 63) == 0)
-            for (int a = 0; a < 3; ++a) {
-                atomicMin(cb + 6 * (size_t)firstR + a, lo[a]);
-                atomicMax(cb + 6 * (size_t)firstR + 3 + a, hi[a]);
-            }
-    } else if (active) {
+        }
+    }
+    const int next = __shfl_down(r, 1, 64);
+    if (active && (lane == 63 || next != r))
         for (int a = 0; a < 3; ++a) {
             atomicMin(cb + 6 * (size_t)r + a, lo[a]);
             atomicMax(cb + 6 * (size_t)r + 3 + a, hi[a]);
         }
-    }
 }
 
 // csrc/host/BVH.h binOf
