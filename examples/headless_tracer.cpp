@@ -80,6 +80,7 @@ int main(int argc, char** argv) {
     std::string experimentFname, out = "frame.png", assets;
     int phaseIdx = 0, frames = 1, positional = 0;
     bool skipUnlit = false;  // shadow rays towards lights behind the surface are not walked (same image)
+    bool rebuildSah = false;  // every mesh BVH is built again on the GPU at upload, cut by the binned surface-area heuristic
     std::vector<int> devices{0};
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -91,6 +92,8 @@ int main(int argc, char** argv) {
             assets = argv[++i];
         else if (a == "--skip-unlit")
             skipUnlit = true;
+        else if (a == "--rebuild-sah")
+            rebuildSah = true;
         else if (a == "--gpus" && i + 1 < argc) {
             // a count ("4": devices 0..3) or a list ("0,0": the same GPU twice, two contexts)
             const std::string v = argv[++i];
@@ -114,7 +117,7 @@ int main(int argc, char** argv) {
             phaseIdx = std::atoi(a.c_str());
             positional++;
         } else {
-            std::fprintf(stderr, "usage: %s [experiment.json [phase]] [--frames N] [--out file.png] [--assets DIR] [--gpus N | --gpus d0,d1,...] [--skip-unlit]\n", argv[0]);
+            std::fprintf(stderr, "usage: %s [experiment.json [phase]] [--frames N] [--out file.png] [--assets DIR] [--gpus N | --gpus d0,d1,...] [--skip-unlit] [--rebuild-sah]\n", argv[0]);
             return 2;
         }
     }
@@ -136,6 +139,10 @@ int main(int argc, char** argv) {
         }
         RayTracer tracer(options);
         tracer.skipUnlitShadowRays = skipUnlit;
+        if (rebuildSah) {
+            tracer.rebuildAtUpload = true;
+            tracer.deviceSplitRule = BVH::BINNED_SAH;
+        }
         initScene(tracer, options, assets);
 
         rt_ctx* ctx = nullptr;

@@ -191,6 +191,11 @@ def test_cpp_driver_on_two_contexts(tmp_path):
         pics.append(np.asarray(Image.open(tmp_path / name).convert("RGBA")))
     assert f"on {2} GPU context(s)" in r.stdout or "on 3 GPU context(s)" in r.stdout
     assert np.array_equal(pics[0], pics[1]) and np.array_equal(pics[0], pics[2])
+    # the same picture from trees the device cut again by surface area (RayTracer::rebuildAtUpload + deviceSplitRule)
+    r = subprocess.run([exe, str(doc), "0", "--frames", "2", "--rebuild-sah", "--out", str(tmp_path / "sah.png")], capture_output=True, text=True, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    sah = np.asarray(Image.open(tmp_path / "sah.png").convert("RGBA"))
+    assert (sah != pics[0]).any(axis=-1).mean() < 1e-3  # (equal-distance ties on shared edges follow the tree's order)
     # the same picture with the shadow rays of lights behind the surface left out (RayTracer::skipUnlitShadowRays), on one and on two contexts
     for gpus, name in (("1", "one_skip.png"), ("0,0", "two_skip.png")):
         r = subprocess.run([exe, str(doc), "0", "--frames", "2", "--gpus", gpus, "--skip-unlit", "--out", str(tmp_path / name)], capture_output=True,
