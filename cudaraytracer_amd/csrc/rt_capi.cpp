@@ -13,7 +13,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <utility>
 #include <vector>
@@ -1001,6 +1003,25 @@ int refitOnDevice(rt_ctx* ctx, rt_scene* sc, const unsigned char* hostBlob, cons
 }  // namespace
 
 namespace {
+// part(k, parts) for k = 0 .. parts - 1, on up to 16 threads when there is enough to do; parts that get no thread (a
+// process limit) run on the calling thread.
+void onThreads(size_t items, const std::function<void(int, int)>& part) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int parts = items < ((size_t)1 << 16) ? 1 : (int)std::min(hw ? hw : 1u, 16u);
+    std::vector<std::thread> pool;
+    std::vector<int> inlineParts;
+    for (int k = 1; k < parts; ++k) {
+        try {
+            pool.emplace_back([&part, k, parts] { part(k, parts); });
+        } catch (const std::system_error&) {
+            inlineParts.push_back(k);
+        }
+    }
+    part(0, parts);
+    for (int k : inlineParts) part(k, parts);
+    for (std::thread& t : pool) t.join();
+}
+
 // The mesh BVH of rt_mesh_bvh_build(RT_BVH_BINNED_SAH, tight bounds) with the cuts decided on the device
 // (rt_set_device_bvh_rule): same node array, same leaf order.  The host keeps the tree - its shape depends on the data -
 // and drives the device level by level (kernels/rt_bvh_build.hip, "Surface-area cuts"); boxes are formed here, by the
@@ -1025,25 +1046,17 @@ int deviceSahBuild(rt_ctx* ctx, const RtMesh& m, int threshold, std::vector<RtLi
             }
     // primitive boxes as csrc/host/BVH.h triangleBox(TIGHT_BOUNDS) forms them, on as many threads as the host builder takes
     std::vector<BoundingBox> boxes((size_t)n);
-    {
-        const unsigned hw = std::thread::hardware_concurrency();
-        const int threads = n < (1 << 16) ? 1 : (int)std::min(hw ? hw : 1u, 16u);
-        auto part = [&](int k) {
-            const size_t from = (size_t)n * k / threads, to = (size_t)n * (k + 1) / threads;
-            for (size_t t = from; t < to; ++t) {
-                BoundingBox b = rt::BVH::emptyBox(rt::BVH::TIGHT_BOUNDS);
-                for (int c = 0; c < 3; ++c) {
-                    const float* p = m.vertices[m.triangles[t].i[c]].position;
-                    b = BoundingBox::unionn(b, rt::Vec3f(p[0], p[1], p[2]));
-                }
-                boxes[t] = b;
+    onThreads((size_t)n, [&](int k, int parts) {
+        const size_t from = (size_t)n * k / parts, to = (size_t)n * (k + 1) / parts;
+        for (size_t t = from; t < to; ++t) {
+            BoundingBox b = rt::BVH::emptyBox(rt::BVH::TIGHT_BOUNDS);
+            for (int c = 0; c < 3; ++c) {
+                const float* p = m.vertices[m.triangles[t].i[c]].position;
+                b = BoundingBox::unionn(b, rt::Vec3f(p[0], p[1], p[2]));
             }
-        };
-        std::vector<std::thread> pool;
-        for (int k = 1; k < threads; ++k) pool.emplace_back(part, k);
-        part(0);
-        for (std::thread& t : pool) t.join();
-    }
+            boxes[t] = b;
+        }
+    });
     tBoxes = now() - t0;
     struct Node {
         int start, end, orderedBase, axis, first, second;  // children: indices into `tree`, -1 for a leaf
@@ -1132,10 +1145,8 @@ int deviceSahBuild(rt_ctx* ctx, const RtMesh& m, int threshold, std::vector<RtLi
         }
     {
         // the leaves: boxes and ordered triangles, each leaf on its own - on several threads for a large mesh
-        const unsigned hw = std::thread::hardware_concurrency();
-        const int threads = n < (1 << 16) ? 1 : (int)std::min(hw ? hw : 1u, 16u);
-        auto part = [&](int k) {
-            const size_t from = tree.size() * k / threads, to = tree.size() * (k + 1) / threads;
+        onThreads((size_t)n, [&](int k, int parts) {
+            const size_t from = tree.size() * k / parts, to = tree.size() * (k + 1) / parts;
             for (size_t t = from; t < to; ++t) {
                 const Node& nd = tree[t];
                 if (nd.first >= 0) continue;
@@ -1152,11 +1163,7 @@ int deviceSahBuild(rt_ctx* ctx, const RtMesh& m, int threshold, std::vector<RtLi
                     out.bbmax[c] = bb.bbmax[c];
                 }
             }
-        };
-        std::vector<std::thread> pool;
-        for (int k = 1; k < threads; ++k) pool.emplace_back(part, k);
-        part(0);
-        for (std::thread& t : pool) t.join();
+        });
     }
     for (int slot = (int)tree.size() - 1; slot >= 0; --slot) {
         const Node& nd = tree[bySlot[slot]];
