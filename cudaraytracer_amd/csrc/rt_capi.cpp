@@ -1226,7 +1226,13 @@ rt_scene* rt_scene_upload(rt_ctx* ctx, const RtSceneDesc* desc) {
         for (int mi = 0; mi < desc->meshCnt; ++mi) {
             if (!builtOnDevice(desc->meshes[mi], &ctx->bvhBuild)) continue;
             const double t1 = now();
-            const int rr = deviceSahBuild(ctx, desc->meshes[mi], ctx->bvhBuild.threshold, builtNodes[mi], builtTriangles[mi], &err);
+            int rr;
+            try {
+                rr = deviceSahBuild(ctx, desc->meshes[mi], ctx->bvhBuild.threshold, builtNodes[mi], builtTriangles[mi], &err);
+            } catch (const std::exception& e) {  // (out of host memory)
+                err = e.what();
+                rr = RT_ERR_LIMIT;
+            }
             if (rr != RT_OK) {
                 fail(ctx, rr, "mesh %d: %s", mi, err.c_str());
                 return nullptr;
