@@ -124,3 +124,25 @@ def test_clumps_of_coinciding_centroids(gpu_ctx, rtlib):
         for s in (a, b):
             if s is not None:
                 gpu_ctx.free_scene(s)
+
+
+def test_small_meshes_and_extreme_thresholds(gpu_ctx):
+    """One to a few hundred triangles, leaves of 1, 2 and 63: a single leaf, a root with two leaves, ranges that fit two leaves
+    (cut where the two boxes' surface is smallest) - blob for blob the host builder's scene."""
+    try:
+        for name in ("soup", "heightfield"):
+            for size in (1, 2, 3, 9, 17, 257):
+                for threshold in (1, 2, 63):
+                    host = rt.HostScene(name, 32, 32, size, 1, 0, tight_bvh=True, sah_bvh=True, leaf_threshold=threshold)
+                    dev = rt.HostScene(name, 32, 32, size, 1, 0, tight_bvh=True, device_bvh=True)
+                    gpu_ctx.set_device_bvh(threshold, True)
+                    gpu_ctx.set_device_bvh_rule(sah=True)
+                    a, b = gpu_ctx.upload(host), gpu_ctx.upload(dev)
+                    try:
+                        assert np.array_equal(blob_of(gpu_ctx, a), blob_of(gpu_ctx, b)), (name, size, threshold)
+                    finally:
+                        gpu_ctx.free_scene(a)
+                        gpu_ctx.free_scene(b)
+    finally:
+        gpu_ctx.set_device_bvh_rule(sah=False)
+        gpu_ctx.set_device_bvh(10, True)
