@@ -36,6 +36,9 @@ def gpu_ctx():
     # min / max box test, then the literal one for rays along axis planes); contexts that tests create themselves keep
     # the default, under which small frames take the literal test in one launch.
     ctx.set_box_test_split(0)
+    # RT_TEST_UNLIT_SKIP=1 runs the whole GPU suite with rt_set_unlit_shadow_skip on: every comparison with the oracle must hold as it is
+    if os.environ.get("RT_TEST_UNLIT_SKIP") == "1":
+        ctx.set_unlit_shadow_skip(True)
     yield ctx
     ctx.close()
 
