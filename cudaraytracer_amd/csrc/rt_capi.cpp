@@ -312,6 +312,25 @@ int relocateRefs(std::vector<RtLinearNode>& recs, uint64_t unitBase, uint32_t pr
     return RT_OK;
 }
 
+// part(k, parts) for k = 0 .. parts - 1, on up to 16 threads when there is enough to do; parts that get no thread (a
+// process limit) run on the calling thread.
+void onThreads(size_t items, const std::function<void(int, int)>& part) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int parts = items < ((size_t)1 << 16) ? 1 : (int)std::min(hw ? hw : 1u, 16u);
+    std::vector<std::thread> pool;
+    std::vector<int> inlineParts;
+    for (int k = 1; k < parts; ++k) {
+        try {
+            pool.emplace_back([&part, k, parts] { part(k, parts); });
+        } catch (const std::system_error&) {
+            inlineParts.push_back(k);
+        }
+    }
+    part(0, parts);
+    for (int k : inlineParts) part(k, parts);
+    for (std::thread& t : pool) t.join();
+}
+
 // A mesh that arrives without BVH nodes gets its BVH on the device.  The tree's shape (median cuts down to
 // `threshold` primitives, csrc/host/BVH.h) follows from the count alone: this writes the depth-first node array
 // with references and leaf ranges but without boxes and axes, and the per-node facts the device build needs.
@@ -554,20 +573,29 @@ int packScene(const RtSceneDesc* d, std::vector<unsigned char>& out, std::string
         const RtMesh& m = d->meshes[mi];
         const DevMesh& dm = meshes[mi];
         std::memcpy(base + dm.offNodes, meshPairs[mi].data(), meshPairs[mi].size() * sizeof(RtLinearNode));
-        std::memcpy(base + dm.offVertices, m.vertices, (size_t)m.vertexCnt * sizeof(RtVertex));
+        // (large meshes: vertices and records on several threads - two gigabytes for ten million de-indexed triangles)
+        const size_t vertexBytes = (size_t)m.vertexCnt * sizeof(RtVertex);
+        onThreads((size_t)m.vertexCnt, [&](int k, int parts) {
+            const size_t from = vertexBytes * k / parts, to = vertexBytes * (k + 1) / parts;
+            std::memcpy(base + dm.offVertices + from, reinterpret_cast<const unsigned char*>(m.vertices) + from, to - from);
+        });
         TriRecord* rec = reinterpret_cast<TriRecord*>(base + dm.offTriRecords);
         const bool onDevice = builtOnDevice(m, builds ? build : nullptr);  // the device build writes this mesh's records
-        for (int t = 0; !onDevice && t < m.triangleCnt; ++t) {
-            const float* p0 = m.vertices[m.triangles[t].i[0]].position;
-            const float* p1 = m.vertices[m.triangles[t].i[1]].position;
-            const float* p2 = m.vertices[m.triangles[t].i[2]].position;
-            for (int k = 0; k < 3; ++k) {
-                rec[t].v0[k] = p0[k];
-                rec[t].e1[k] = p1[k] - p0[k];  // same fp32 subtraction the reference does per test
-                rec[t].e2[k] = p2[k] - p0[k];
-                rec[t].idx[k] = m.triangles[t].i[k];
-            }
-        }
+        if (!onDevice)
+            onThreads((size_t)m.triangleCnt, [&](int part, int parts) {
+                const size_t from = (size_t)m.triangleCnt * part / parts, to = (size_t)m.triangleCnt * (part + 1) / parts;
+                for (size_t t = from; t < to; ++t) {
+                    const float* p0 = m.vertices[m.triangles[t].i[0]].position;
+                    const float* p1 = m.vertices[m.triangles[t].i[1]].position;
+                    const float* p2 = m.vertices[m.triangles[t].i[2]].position;
+                    for (int k = 0; k < 3; ++k) {
+                        rec[t].v0[k] = p0[k];
+                        rec[t].e1[k] = p1[k] - p0[k];  // same fp32 subtraction the reference does per test
+                        rec[t].e2[k] = p2[k] - p0[k];
+                        rec[t].idx[k] = m.triangles[t].i[k];
+                    }
+                }
+            });
         const RtTexture* tex[3] = {&m.diffuse, &m.normals, &m.specular};
         for (int k = 0; k < 3; ++k)
             std::memcpy(base + dm.offTex[k], tex[k]->data, (size_t)tex[k]->width * tex[k]->height * 4);
@@ -1003,25 +1031,6 @@ int refitOnDevice(rt_ctx* ctx, rt_scene* sc, const unsigned char* hostBlob, cons
 }  // namespace
 
 namespace {
-// part(k, parts) for k = 0 .. parts - 1, on up to 16 threads when there is enough to do; parts that get no thread (a
-// process limit) run on the calling thread.
-void onThreads(size_t items, const std::function<void(int, int)>& part) {
-    const unsigned hw = std::thread::hardware_concurrency();
-    const int parts = items < ((size_t)1 << 16) ? 1 : (int)std::min(hw ? hw : 1u, 16u);
-    std::vector<std::thread> pool;
-    std::vector<int> inlineParts;
-    for (int k = 1; k < parts; ++k) {
-        try {
-            pool.emplace_back([&part, k, parts] { part(k, parts); });
-        } catch (const std::system_error&) {
-            inlineParts.push_back(k);
-        }
-    }
-    part(0, parts);
-    for (int k : inlineParts) part(k, parts);
-    for (std::thread& t : pool) t.join();
-}
-
 // The mesh BVH of rt_mesh_bvh_build(RT_BVH_BINNED_SAH, tight bounds) with the cuts decided on the device
 // (rt_set_device_bvh_rule): same node array, same leaf order.  The host keeps the tree - its shape depends on the data -
 // and drives the device level by level (kernels/rt_bvh_build.hip, "Surface-area cuts"); boxes are formed here, by the
