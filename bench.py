@@ -184,6 +184,22 @@ def time_frames(ctx, render, frames, in_flight, surfaces):
     return wall, [k_ms / n] + [x / n for x in st]
 
 
+def roofline_factors(prof, flops):
+    """The roofline fraction as a product of three measured factors (committed PMC passes of the same workload): how often
+    a SIMD issues a vector instruction against the peak's one per two cycles, how many of the 64 lanes an instruction runs
+    with, and how many of the counted flops an active lane's instruction carries against the peak's two (a fused multiply-add)."""
+    need = ("valu_insts_per_launch", "valu_thread_cycles_per_launch", "gui_active_cycles_per_launch")
+    if not prof or any(k not in prof for k in need):
+        return None
+    insts, lanes, cycles = (prof[k] for k in need)
+    simd_cycles = 256 * 4 * cycles / 8  # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+    issue, lane_use, carried = insts / simd_cycles / 0.5, lanes / insts / 64, flops / lanes / 2
+    return {"issue_rate_vs_peak": issue, "lanes_per_instruction_of_64": lane_use, "flops_per_active_lane_instruction_of_2": carried,
+            "product": issue * lane_use * carried,
+            "note": "product = achieved / peak at the profiled launch's clock (GRBM_GUI_ACTIVE / 8 XCDs over its duration); counters from the "
+                    "committed rocprofv3 passes, flops from this run's counter build"}
+
+
 def other_workload(ctx, torch, dev, label, scene_args, scene_kwargs, nf):
     """In-order and in-flight figures of another workload of the scope table, on the same kernels.
     scene_kwargs["upload_refit"]: upload with rt_set_upload_refit on (boxes recomputed on the device);
@@ -643,6 +659,7 @@ def main():
                          "instructions": {"valu_per_launch": prof.get("valu_insts_per_launch"),
                                           "valu_per_box_pair_or_triangle_phase": None,
                                           "source": prof_src if prof else None},
+                         "factors": roofline_factors(prof, closest_flops // world),
                          "other_kernels": {"traceKernel<true,false,false,false> (shadow, any hit)": {"achieved": tflops(shadow_flops, shadow_ms), "unit": "TFLOP/s",
                                                                                          "algorithmic_flops_per_launch": shadow_flops // world,
                                                                                          "launch_ms": shadow_ms},

@@ -65,6 +65,10 @@ for k, d in sorted(agg.items()):
         traffic[k] = {"fetch_size_bytes_raw": fetch, "write_size_bytes": write, "hbm_bytes_per_launch": 2 * fetch + write}
         if "SQ_INSTS_VALU" in d:  # wavefront-wide vector instructions per launch (4 SIMD cycles each)
             traffic[k]["valu_insts_per_launch"] = sum(d["SQ_INSTS_VALU"]) / len(d["SQ_INSTS_VALU"])
+        if "SQ_THREAD_CYCLES_VALU" in d:  # the same instructions counted per active lane
+            traffic[k]["valu_thread_cycles_per_launch"] = sum(d["SQ_THREAD_CYCLES_VALU"]) / len(d["SQ_THREAD_CYCLES_VALU"])
+        if "GRBM_GUI_ACTIVE" in d:  # busy cycles of the launch, summed over the 8 XCDs
+            traffic[k]["gui_active_cycles_per_launch"] = sum(d["GRBM_GUI_ACTIVE"]) / len(d["GRBM_GUI_ACTIVE"])
         print(f"   => HBM bytes per launch: 2 x {fetch/1e6:.1f} MB + {write/1e6:.1f} MB = {(2*fetch+write)/1e6:.1f} MB")
         # the same figures, unrounded, as they go into the traffic table
         print("   => table: " + json.dumps(traffic[k], sort_keys=True))
